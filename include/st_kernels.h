@@ -1,0 +1,160 @@
+/*
+ * st_kernels.h — C-ABI of libst_kernels.so: the MI355X (gfx950) kernels under the gradient-guided
+ * `--attack` loop of Facico/style-transfer.
+ *
+ * The reference has no FFI of its own for this path (it is in-process PyTorch); each
+ * entry point below names the reference Python it replaces (file:line under
+ * /root/reference/method/yelp/).  All pointers are DEVICE pointers unless the parameter is named
+ * *_host or is a weights struct (host struct holding device pointers).  Every function returns 0 on
+ * success and a negative ST_E* code on failure (st_last_error() gives the text); nothing throws
+ * across the boundary; the caller owns every buffer; `stream` is a hipStream_t (0 = default
+ * stream).  Kernels are launched asynchronously on `stream`; only st_decode_greedy synchronises it
+ * (to read back the live-sentence count, see below).
+ *
+ * Arithmetic type everywhere: IEEE f32 (the reference's dtype), matrix products on the f32-input
+ * MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain).  Token ids are int32.
+ */
+#ifndef ST_KERNELS_H
+#define ST_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_OK 0
+#define ST_EINVAL (-1)   /* bad argument / unsupported shape          */
+#define ST_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define ST_ENOMEM (-3)   /* workspace too small                        */
+
+#define ST_D 256          /* latent/model width the kernels are specialised for (main.py:70,73) */
+#define ST_MAX_LAYERS 4
+#define ST_MAX_REFS 16    /* max like / unlike sentences per origin (reference data: 10 + 10)   */
+
+/* library identification / error text (no reference counterpart: ABI plumbing) */
+int st_abi_version(void);
+const char* st_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) Style scorer: SiameseNet + Predictor + contrastive score + backward-to-latent + Adam.
+ * ------------------------------------------------------------------------------------------- */
+
+/* SiameseNet (siamese_contrastive.py:29-63) and Predictor (:66-86) in eval mode.  BatchNorm1d
+ * (eval, running stats) is folded into the preceding Linear by the host:  W' = s*W, b' = s*b + t
+ * with s = gamma/sqrt(var+eps), t = beta - mean*s.   Each matrix is given row-major [out,in] (`w`)
+ * AND transposed [in,out] (`wt`, used by the backward pass).  The Predictor hidden width (100) is
+ * zero-padded to 128 by the host.                                                              */
+typedef struct StScorerWeights {
+  const float *s1_w, *s1_wt, *s1_b;   /* 256 -> 512 (+BN1 folded), ReLU          */
+  const float *s2_w, *s2_wt, *s2_b;   /* 512 -> 512 (+BN2 folded), ReLU          */
+  const float *s3_w, *s3_wt, *s3_b;   /* 512 -> 256                              */
+  const float *p1_w, *p1_wt, *p1_b;   /* 256 -> 128 (100 padded; +BN folded), LeakyReLU(0.2) */
+  const float *p2_w, *p2_wt, *p2_b;   /* 128 -> 256                              */
+} StScorerWeights;
+
+/* z = SiameseNet(x) for n rows (replaces batch_forward(1, siamese_net, like/unlike_latent),
+ * siamese_contrastive.py:381-382, which the reference recomputes every iteration although it is
+ * loop-invariant).  If unit != 0 each row is divided by max(||z||, 1e-8) (F.cosine_similarity's
+ * normalisation) so the edit step can use dot products.                                          */
+int st_scorer_embed(const StScorerWeights* w, const float* x, float* z, int n, int unit, void* stream);
+
+/* flags for st_scorer_edit_step */
+#define ST_F_NOT_NLL 1        /* --not_nll       (siamese_contrastive.py:424-436) */
+#define ST_F_SIMPLEST 2       /* --simplest_siamese (:384-400): no Predictor       */
+#define ST_F_JUST_USE_ONE 4   /* --just_use_one  (:449-452)                        */
+
+/* One edit iteration for B sentences (replaces get_contrastive_loss + `loss=-(loss); zero_grad();
+ * loss.backward(); ori_optimizer.step()`, siamese_contrastive.py:796-810, with torch.optim.Adam
+ * defaults beta=(0.9,0.999), eps=1e-8, built per sentence at :780-781).
+ *   latent, adam_m, adam_v : [B,256] in/out      like_z / unlike_z : [B,n_pos,256] / [B,n_neg,256]
+ *   unit vectors from st_scorer_embed(unit=1)     lr : [B] (pos_victim_lr / neg_victim_lr, :740)
+ *   step : [B] Adam step count BEFORE this call (incremented here)   active : [B] 0 = skip row
+ *   loss_out : [B] the value get_contrastive_loss returns (before the sign flip), may be NULL
+ *   grad_out : [B,256] d(-loss)/d latent, may be NULL (parity tests)                              */
+int st_scorer_edit_step(const StScorerWeights* w, float* latent, float* adam_m, float* adam_v,
+                        const float* like_z, const float* unlike_z, int n_pos, int n_neg,
+                        const float* lr, int* step, const uint8_t* active, int B, float tau,
+                        int flags, float* loss_out, float* grad_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) Greedy decode with the Transformer autoencoder's decoder (KV-cached).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct StDecLayer {
+  const float *ln0_a, *ln0_b;          /* sublayer[0].norm  (model.py:97-108 LayerNorm)         */
+  const float *wqkv, *bqkv;            /* self_attn.linears[0..2] stacked: [768,256], [768]     */
+  const float *wo, *bo;                /* self_attn.linears[3]                                  */
+  const float *xv_w, *xv_b;            /* src_attn.linears[2] (value projection)                */
+  const float *xo_w, *xo_b;            /* src_attn.linears[3]; q/k projections and sublayer[1].norm
+                                          cannot influence the output: memory has ONE position so
+                                          softmax == 1 (model.py:264-269)         */
+  const float *ln2_a, *ln2_b;          /* sublayer[2].norm                                      */
+  const float *w1, *b1, *w2, *b2;      /* feed_forward.w_1 [d_ff,256], w_2 [256,d_ff]           */
+} StDecLayer;
+
+typedef struct StDecoderWeights {
+  int32_t d_model, n_heads, d_ff, n_layers, vocab, pe_rows;
+  const float* emb;                    /* tgt_embed.0.lut.weight [V,256]                        */
+  const float* pe;                     /* tgt_embed.1.pe [pe_rows,256]                          */
+  const float *lnf_a, *lnf_b;          /* decoder.norm                                          */
+  const float *gen_w, *gen_b;          /* generator.proj [V,256], [V]                           */
+  StDecLayer layer[ST_MAX_LAYERS];
+} StDecoderWeights;
+
+/* bytes of device workspace st_decode_greedy needs for B sentences */
+size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len);
+
+/* options for st_decode_greedy */
+#define ST_DEC_EARLY_EXIT 1   /* stop a sentence at its first EOS/PAD token (output-equivalent:
+                                 data.py:43-52 truncates there); off = the reference's fixed
+                                 max_len-1 steps                                                 */
+
+/* ys = EncoderDecoder.greedy_decode(latent, max_len, start_id) (model.py:271-299) for B sentences.
+ *   latent [B,256]   out_ids [B,max_len-1] int32 (positions after an early exit hold 0 = PAD)
+ *   top2gap [B,max_len-1] f32 or NULL: best minus second-best logit at each emitted token (the
+ *   record that lets a divergence be traced to an argmax near-tie)
+ *   n_steps_host (host int*, may be NULL): number of decode steps actually run.
+ * Synchronises `stream` once per `sync_every` steps to read the live count (>=1).               */
+int st_decode_greedy(const StDecoderWeights* w, const float* latent, int B, int max_len, int bos,
+                     int eos, int pad, int options, int sync_every, int32_t* out_ids,
+                     float* top2gap, void* workspace, size_t workspace_bytes, int* n_steps_host,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) Generator GEMM + argmax: ids[r] = argmax_v( LN(h[r]) . W[v] + b[v] )  (model.py:200-207 +
+ * torch.max(prob, dim=1), :290-292; log_softmax is argmax-invariant and skipped; ties -> lowest
+ * index).  ln_a/ln_b may be NULL (no LayerNorm).  scratch: n*ST_ARGMAX_SPLITS*16 bytes.          */
+#define ST_ARGMAX_SPLITS 4
+int st_gemm_argmax(const float* h, const float* ln_a, const float* ln_b, const float* W,
+                   const float* b, int n, int V, int32_t* ids, float* best, float* gap,
+                   void* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) Text-change detection (siamese_contrastive.py:816-839 + data.py:43-52), on ids.
+ * For each active sentence: the decoded row `new_ids` and the accepted row `acc_ids` are compared
+ * as texts (prefix up to the first EOS/PAD, ids >= vocab -> UNK, ids mapped through `canon`
+ * (id -> first id with the same word) when canon != NULL).  If different: acc_ids <- new_ids,
+ * changed[s] = 1, n_changes[s] += 1, and active[s] <- 0 once n_changes[s] >= max_change.
+ * rec_ids (may be NULL) [B,T] receives the accepted row after this iteration.                   */
+int st_accept_changes(const int32_t* new_ids, int32_t* acc_ids, int T, int B, int vocab, int unk,
+                      int eos, int pad, const int32_t* canon, int max_change, int32_t* n_changes,
+                      uint8_t* changed, uint8_t* active, int32_t* rec_ids, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5) In-batch InfoNCE similarity loss (train_ae_model_constraint, siamese_contrastive.py:1060-1069):
+ *   sim = cos(ori[i], like[j]) / tau  for i in [0,Bq), j in [0,Bk);  loss[i] = -log_softmax(sim[i])[row_offset+i]
+ * The [Bq,Bk] matrix is never written to memory (online softmax).  lse[i] = logsumexp(sim[i]) is
+ * kept for the backward.  bwd: given g[i] = dL/dloss[i], accumulates d_ori [Bq,256], d_like [Bk,256]
+ * (d_like is ADDED to: caller zeroes it; rank-partial sums are reduce-scattered by the host).   */
+int st_simloss_fwd(const float* ori, const float* like, int Bq, int Bk, float tau, int row_offset,
+                   float* loss, float* lse, void* scratch, size_t scratch_bytes, void* stream);
+int st_simloss_bwd(const float* ori, const float* like, int Bq, int Bk, float tau, int row_offset,
+                   const float* lse, const float* g, float* d_ori, float* d_like, void* scratch,
+                   size_t scratch_bytes, void* stream);
+size_t st_simloss_scratch_bytes(int Bq, int Bk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST_KERNELS_H */

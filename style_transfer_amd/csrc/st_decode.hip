@@ -1,0 +1,334 @@
+// KV-cached greedy decode of the Transformer autoencoder's decoder (replaces
+// EncoderDecoder.greedy_decode, /root/reference/method/yelp/model.py:271-299, which re-runs the whole
+// decoder over the growing prefix at every step) + generator GEMM with fused argmax (model.py:200-207,
+// :290-292).  One launch sequence per decode step over the COMPACTED list of live sentences.
+#include "st_gemm.h"
+
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void st_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* st_last_error(void) { return g_err; }
+extern "C" int st_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// x[r] = emb[token(s)] * sqrt(d) + pe[pos]   (model.py:126-133 Embeddings, :75-94 PositionalEncoding)
+// one wave per live row; also resets the *next* live counter (ping-pong, see st_decode_greedy).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
+                                                    const int* __restrict__ idx, const int* __restrict__ n_dev,
+                                                    int* __restrict__ n_next, const int32_t* __restrict__ ys, int T,
+                                                    int pos, int bos, int vocab, float* __restrict__ x) {
+  const int n = *n_dev;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_next = 0;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int s = idx[r];
+  int tok = pos == 0 ? bos : ys[(size_t)s * T + pos - 1];
+  tok = min(max(tok, 0), vocab - 1);
+  const f32x4 e = *(const f32x4*)(emb + (size_t)tok * 256 + lane * 4);
+  const f32x4 p = *(const f32x4*)(pe + (size_t)pos * 256 + lane * 4);
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-query causal self-attention over the cache (model.py:18-27 attention, :30-60 MHA; h=4, d_k=64)
+// block = one live row, wave = head, lane j = key position j (pos+1 <= 64 keys), then lane d = out dim.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
+                                                        const float* __restrict__ vbase, long kv_stride,
+                                                        const int* __restrict__ idx, const int* __restrict__ n_dev,
+                                                        int pos, float* __restrict__ out) {
+  __shared__ __align__(16) float qs[256];
+  const int r = blockIdx.x;
+  if (r >= *n_dev) return;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  qs[tid] = q[(size_t)r * 256 + tid];
+  __syncthreads();
+  const long s = idx[r];
+  const float* K = kbase + s * kv_stride + h * 64;
+  const float* V = vbase + s * kv_stride + h * 64;
+  float sc = -INFINITY;
+  if (lane <= pos) {
+    const float* kr = K + (size_t)lane * 256;
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4 kv = *(const f32x4*)(kr + d);
+      const f32x4 qv = *(const f32x4*)(qs + h * 64 + d);
+      acc = fmaf(qv.x, kv.x, acc);
+      acc = fmaf(qv.y, kv.y, acc);
+      acc = fmaf(qv.z, kv.z, acc);
+      acc = fmaf(qv.w, kv.w, acc);
+    }
+    sc = acc * 0.125f;  // / sqrt(d_k)
+  }
+  const float m = wave_max(sc);
+  const float e = lane <= pos ? expf(sc - m) : 0.0f;
+  const float p = e / wave_sum(e);
+  float o = 0.0f;
+  for (int j = 0; j <= pos; ++j) o = fmaf(__shfl(p, j, 64), V[(size_t)j * 256 + lane], o);
+  out[(size_t)r * 256 + h * 64 + lane] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge the generator's per-split (best, index, second) partials; emit the token; keep the sentence
+// live unless it produced EOS/PAD (early exit) or this was the last step.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finish_kernel(const float4* __restrict__ partial, int nsplit,
+                                                     const int* __restrict__ idx, const int* __restrict__ n_dev,
+                                                     int32_t* __restrict__ ys, float* __restrict__ gap, int T, int pos,
+                                                     int eos, int pad, int early, int last, int* __restrict__ idx_next,
+                                                     int* __restrict__ n_next) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= *n_dev) return;
+  float4 p0 = partial[(size_t)r * nsplit];
+  Top2 t = {p0.x, __float_as_int(p0.y), p0.z};
+  for (int k = 1; k < nsplit; ++k) {
+    const float4 pk = partial[(size_t)r * nsplit + k];
+    Top2 u = {pk.x, __float_as_int(pk.y), pk.z};
+    t = top2_merge(t, u);
+  }
+  const int s = idx[r];
+  ys[(size_t)s * T + pos] = t.i1;
+  if (gap) gap[(size_t)s * T + pos] = t.m1 - t.m2;
+  const bool done = last || (early && (t.i1 == eos || t.i1 == pad));
+  if (!done) idx_next[atomicAdd(n_next, 1)] = s;
+}
+
+__global__ void iota_kernel(int* idx, int* n_dev, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = i;
+  if (i == 0) *n_dev = n;
+}
+
+// standalone merge for st_gemm_argmax
+__global__ __launch_bounds__(256) void argmax_merge_kernel(const float4* __restrict__ partial, int nsplit, int n,
+                                                           int32_t* __restrict__ ids, float* __restrict__ best,
+                                                           float* __restrict__ gap) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  float4 p0 = partial[(size_t)r * nsplit];
+  Top2 t = {p0.x, __float_as_int(p0.y), p0.z};
+  for (int k = 1; k < nsplit; ++k) {
+    const float4 pk = partial[(size_t)r * nsplit + k];
+    Top2 u = {pk.x, __float_as_int(pk.y), pk.z};
+    t = top2_merge(t, u);
+  }
+  ids[r] = t.i1;
+  if (best) best[r] = t.m1;
+  if (gap) gap[r] = t.m1 - t.m2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+static int launch_panel(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)panel_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               ST_PANEL_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  dim3 grid((n_bound + 63) / 64, splits);
+  hipLaunchKernelGGL(panel_gemm_kernel<EPI>, grid, dim3(512), ST_PANEL_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+template <int EPI>
+static int launch_kloop(const GemmArgs& a, int n_bound, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)kloop_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               ST_KLOOP_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  dim3 grid((n_bound + 127) / 128, (a.N + 127) / 128);
+  hipLaunchKernelGGL(kloop_gemm_kernel<EPI>, grid, dim3(256), ST_KLOOP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+#define ST_TRY(x)            \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != ST_OK) return rc_; \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DecodeWs {
+  float* kv;       // [B][L][2][T][256]
+  float* x;        // [B][256]
+  float* q;        // [B][256]
+  float* att;      // [B][256]
+  float* h;        // [B][d_ff]
+  float* cc;       // [L][B][256] cross-attention constants
+  float4* partial; // [B][GEN_SPLITS]
+  int* idx[2];     // [B]
+  int* cnt;        // [2]
+  size_t total;
+};
+#define ST_GEN_SPLITS 4
+
+static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base) {
+  DecodeWs ws;
+  const int T = max_len - 1, L = w->n_layers;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  ws.kv = (float*)take((size_t)B * L * 2 * T * 256 * 4);
+  ws.x = (float*)take((size_t)B * 256 * 4);
+  ws.q = (float*)take((size_t)B * 256 * 4);
+  ws.att = (float*)take((size_t)B * 256 * 4);
+  ws.h = (float*)take((size_t)B * w->d_ff * 4);
+  ws.cc = (float*)take((size_t)L * B * 256 * 4);
+  ws.partial = (float4*)take((size_t)B * ST_GEN_SPLITS * 16);
+  ws.idx[0] = (int*)take((size_t)B * 4);
+  ws.idx[1] = (int*)take((size_t)B * 4);
+  ws.cnt = (int*)take(256);
+  ws.total = off;
+  return ws;
+}
+
+static int check_weights(const StDecoderWeights* w, int max_len) {
+  ST_CHECK_ARG(w != nullptr, "weights struct is NULL");
+  ST_CHECK_ARG(w->d_model == ST_D, "d_model=%d unsupported (kernels are specialised for %d)", w->d_model, ST_D);
+  ST_CHECK_ARG(w->n_heads == 4, "n_heads=%d unsupported (4)", w->n_heads);
+  ST_CHECK_ARG(w->d_ff > 0 && w->d_ff % 32 == 0, "d_ff=%d must be a positive multiple of 32", w->d_ff);
+  ST_CHECK_ARG(w->n_layers >= 1 && w->n_layers <= ST_MAX_LAYERS, "n_layers=%d out of range", w->n_layers);
+  ST_CHECK_ARG(w->vocab >= 4, "vocab=%d too small", w->vocab);
+  ST_CHECK_ARG(max_len >= 2 && max_len - 1 <= 64, "max_len=%d unsupported (decode length max_len-1 must be <= 64)", max_len);
+  ST_CHECK_ARG(w->pe_rows >= max_len - 1, "pe_rows=%d < decode length %d", w->pe_rows, max_len - 1);
+  ST_CHECK_ARG(w->emb && w->pe && w->lnf_a && w->lnf_b && w->gen_w && w->gen_b, "NULL weight pointer");
+  for (int l = 0; l < w->n_layers; ++l) {
+    const StDecLayer& y = w->layer[l];
+    ST_CHECK_ARG(y.ln0_a && y.ln0_b && y.wqkv && y.bqkv && y.wo && y.bo && y.xv_w && y.xv_b && y.xo_w && y.xo_b &&
+                     y.ln2_a && y.ln2_b && y.w1 && y.b1 && y.w2 && y.b2,
+                 "NULL weight pointer in layer %d", l);
+  }
+  return ST_OK;
+}
+
+extern "C" size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len) {
+  if (!w || B <= 0 || max_len < 2) return 0;
+  return carve(w, B, max_len, nullptr).total;
+}
+
+extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, int B, int max_len, int bos, int eos,
+                                int pad, int options, int sync_every, int32_t* out_ids, float* top2gap,
+                                void* workspace, size_t workspace_bytes, int* n_steps_host, void* stream) {
+  ST_TRY(check_weights(w, max_len));
+  ST_CHECK_ARG(B >= 0, "B=%d", B);
+  if (n_steps_host) *n_steps_host = 0;
+  if (B == 0) return ST_OK;
+  ST_CHECK_ARG(latent && out_ids && workspace, "NULL buffer");
+  ST_CHECK_ARG(sync_every >= 1, "sync_every=%d must be >= 1", sync_every);
+  hipStream_t st = (hipStream_t)stream;
+  const int T = max_len - 1, L = w->n_layers;
+  DecodeWs ws = carve(w, B, max_len, (char*)workspace);
+  if (ws.total > workspace_bytes) {
+    st_set_error("workspace too small: need %zu bytes, have %zu", ws.total, workspace_bytes);
+    return ST_ENOMEM;
+  }
+  const int early = (options & ST_DEC_EARLY_EXIT) ? 1 : 0;
+  const long kv_stride = (long)L * 2 * T * 256;
+
+  ST_HIP(hipMemsetAsync(out_ids, 0, (size_t)B * T * 4, st));  // PAD after an early exit
+  if (top2gap) ST_HIP(hipMemsetAsync(top2gap, 0, (size_t)B * T * 4, st));
+  hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.idx[0], ws.cnt + 0, B);
+  ST_LAUNCH_CHECK();
+
+  // cross-attention constants: cc[l] = (latent Wv^T + bv) Wo^T + bo   (one key => softmax == 1)
+  for (int l = 0; l < L; ++l) {
+    GemmArgs g = {};
+    g.X = latent; g.n_host = B; g.W = w->layer[l].xv_w; g.bias = w->layer[l].xv_b; g.N = 256;
+    g.out = ws.att; g.ldo = 256;
+    ST_TRY(launch_panel<EPI_BIAS>(g, B, 1, st));
+    g.X = ws.att; g.W = w->layer[l].xo_w; g.bias = w->layer[l].xo_b; g.out = ws.cc + (size_t)l * B * 256;
+    ST_TRY(launch_panel<EPI_BIAS>(g, B, 1, st));
+  }
+
+  int n_bound = B;
+  int cur = 0;
+  int steps = 0;
+  for (int pos = 0; pos < T && n_bound > 0; ++pos) {
+    const int* idx = ws.idx[cur];
+    const int* n_dev = ws.cnt + cur;
+    hipLaunchKernelGGL(embed_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, w->emb, w->pe, idx, n_dev,
+                       ws.cnt + (cur ^ 1), out_ids, T, pos, bos, w->vocab, ws.x);
+    ST_LAUNCH_CHECK();
+    for (int l = 0; l < L; ++l) {
+      const StDecLayer& y = w->layer[l];
+      float* kb = ws.kv + (size_t)(l * 2 + 0) * T * 256;
+      float* vb = ws.kv + (size_t)(l * 2 + 1) * T * 256;
+      GemmArgs g = {};
+      g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
+      g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
+      g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
+      ST_TRY(launch_panel<EPI_QKV>(g, n_bound, 3, st));
+      hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
+                         ws.att);
+      ST_LAUNCH_CHECK();
+      GemmArgs o = {};
+      o.X = ws.att; o.n_dev = n_dev; o.n_host = n_bound; o.W = y.wo; o.bias = y.bo; o.N = 256;
+      o.out = ws.x; o.ldo = 256; o.resid = ws.x; o.cconst = ws.cc + (size_t)l * B * 256; o.ld_cc = 256; o.idx = idx;
+      ST_TRY(launch_panel<EPI_RESID>(o, n_bound, 1, st));
+      GemmArgs f1 = {};
+      f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
+      f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
+      ST_TRY(launch_panel<EPI_RELU>(f1, n_bound, (w->d_ff + 255) / 256, st));
+      GemmArgs f2 = {};
+      f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
+      f2.out = ws.x; f2.ldo = 256; f2.resid = ws.x;
+      ST_TRY(launch_kloop<EPI_RESID>(f2, n_bound, st));
+    }
+    GemmArgs gg = {};
+    gg.X = ws.x; gg.n_dev = n_dev; gg.n_host = n_bound; gg.ln_a = w->lnf_a; gg.ln_b = w->lnf_b;
+    gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
+    ST_TRY(launch_panel<EPI_ARGMAX>(gg, n_bound, ST_GEN_SPLITS, st));
+    hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, ST_GEN_SPLITS, idx,
+                       n_dev, out_ids, top2gap, T, pos, eos, pad, early, pos == T - 1 ? 1 : 0, ws.idx[cur ^ 1],
+                       ws.cnt + (cur ^ 1));
+    ST_LAUNCH_CHECK();
+    cur ^= 1;
+    ++steps;
+    if (early && ((pos + 1) % sync_every == 0) && pos + 1 < T) {
+      int live = 0;
+      ST_HIP(hipMemcpyAsync(&live, ws.cnt + cur, sizeof(int), hipMemcpyDeviceToHost, st));
+      ST_HIP(hipStreamSynchronize(st));
+      n_bound = live;
+    }
+  }
+  if (n_steps_host) *n_steps_host = steps;
+  return ST_OK;
+}
+
+extern "C" int st_gemm_argmax(const float* h, const float* ln_a, const float* ln_b, const float* W, const float* b,
+                              int n, int V, int32_t* ids, float* best, float* gap, void* scratch, void* stream) {
+  ST_CHECK_ARG(n >= 0 && V >= 1, "n=%d V=%d", n, V);
+  if (n == 0) return ST_OK;
+  ST_CHECK_ARG(h && W && b && ids && scratch, "NULL buffer");
+  ST_CHECK_ARG((ln_a == nullptr) == (ln_b == nullptr), "ln_a and ln_b must both be given or both NULL");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs gg = {};
+  gg.X = h; gg.n_host = n; gg.ln_a = ln_a; gg.ln_b = ln_b; gg.W = W; gg.bias = b; gg.N = V;
+  gg.partial = (float4*)scratch;
+  ST_TRY(launch_panel<EPI_ARGMAX>(gg, n, ST_ARGMAX_SPLITS, st));
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float4*)scratch,
+                     ST_ARGMAX_SPLITS, n, ids, best, gap);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}

@@ -1,0 +1,319 @@
+// Fused style-scorer step: SiameseNet (+Predictor) forward, contrastive score against the like /
+// unlike unit vectors, backward to the latent, Adam update — one launch, one 32-sentence tile per
+// workgroup, every intermediate in LDS.  Replaces get_contrastive_loss + loss.backward() +
+// Adam.step() (/root/reference/method/yelp/siamese_contrastive.py:367-453, :796-810).
+//
+// Only d(loss)/d(latent) is needed, so the backward pass needs no stored activations — just the
+// ReLU / LeakyReLU sign masks (kept as ballot bit-words) and the transposed weights.
+// Products run on v_mfma_f32_32x32x2_f32 (exact f32): M = 32 sentences, A from LDS, B (weights)
+// straight from L2 in the lane layout of st_gemm.h (weights are 2.3 MB, read once per tile).
+#include "st_common.h"
+
+#define SC_LD 516        // activation row stride in floats (512 + 4; = 4 mod 64 -> conflict-free b128)
+#define SC_ROWS 32
+#define SC_BUF (SC_ROWS * SC_LD)
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+enum { BWD_NONE = 0, BWD_RELU = 1, BWD_LRELU = 2 };
+
+// Y[32,N] = X[32,K] . W[N,K]^T, wave w takes 32-column chunks w, w+4, ...
+//  forward  (FWD=true):  y = act(acc + bias[col]); sign bits of the pre-activation -> bits[row][chunk]
+//  backward (FWD=false): y = acc * act'(bits[row][chunk])
+template <int K, int N, bool FWD, int ACT>
+__device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float* __restrict__ Ys,
+                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                            uint32_t* __restrict__ bits, int bits_ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int c = wave; c < N / 32; c += 4) {
+    f32x16 acc = {0};
+    const float* xr = Xs + l31 * SC_LD + 4 * half;
+    const float* wr = W + (size_t)(c * 32 + l31) * K + 4 * half;
+#pragma unroll 8
+    for (int kg = 0; kg < K / 8; ++kg) {
+      const f32x4 a = *(const f32x4*)(xr + kg * 8);
+      const f32x4 b = *(const f32x4*)(wr + kg * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
+    }
+    const int col = c * 32 + l31;
+    const float bv = FWD ? bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mfma32_row(r, lane);
+      float v = acc[r] + bv;
+      if (FWD) {
+        if (ACT != ACT_NONE) {
+          const bool on = v > 0.0f;
+          const unsigned long long bal = __ballot(on);
+          if (lane == 0) {
+            const int r0 = (r & 3) + 8 * (r >> 2);
+            bits[r0 * bits_ld + c] = (uint32_t)bal;
+            bits[(r0 + 4) * bits_ld + c] = (uint32_t)(bal >> 32);
+          }
+          v = on ? v : (ACT == ACT_RELU ? 0.0f : 0.2f * v);
+        }
+      } else {
+        if (ACT != BWD_NONE) {
+          const bool on = (bits[row * bits_ld + c] >> l31) & 1u;
+          v = on ? v : (ACT == BWD_RELU ? 0.0f : 0.2f * v);
+        }
+      }
+      Ys[row * SC_LD + col] = v;
+    }
+  }
+}
+
+struct ScorerArgs {
+  StScorerWeights w;
+  // embed mode
+  const float* x;   // [n,256]
+  float* z;         // [n,256]
+  int n;
+  int unit;
+  // edit mode
+  float* latent;
+  float* adam_m;
+  float* adam_v;
+  const float* like_z;
+  const float* unlike_z;
+  int n_pos, n_neg;
+  const float* lr;
+  int* step;
+  const uint8_t* active;
+  float tau;
+  int flags;
+  float* loss_out;
+  float* grad_out;
+};
+
+template <bool EDIT>
+__global__ __launch_bounds__(256) void scorer_kernel(ScorerArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* bufA = smem;
+  float* bufB = smem + SC_BUF;
+  uint32_t* bits1 = (uint32_t*)(smem + 2 * SC_BUF);  // [32][16]
+  uint32_t* bits2 = bits1 + 32 * 16;                 // [32][16]
+  uint32_t* bitsq = bits2 + 32 * 16;                 // [32][4]
+  float* cosv = (float*)(bitsq + 32 * 4);            // [32][32]
+  float* coef = cosv + 32 * 32;                      // [32][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.n;
+  const int m0 = blockIdx.x * SC_ROWS;
+  if (m0 >= n) return;
+  const float* xin = EDIT ? a.latent : a.x;
+
+  // latent tile -> bufA (32 rows x 64 float4 = 2048, 8 per thread)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = tid + i * 256;
+    const int r = f >> 6, c4 = f & 63;
+    *(f32x4*)(bufA + r * SC_LD + c4 * 4) = *(const f32x4*)(xin + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+  }
+  __syncthreads();
+  tile_linear<256, 512, true, ACT_RELU>(bufA, bufB, a.w.s1_w, a.w.s1_b, bits1, 16);
+  __syncthreads();
+  tile_linear<512, 512, true, ACT_RELU>(bufB, bufA, a.w.s2_w, a.w.s2_b, bits2, 16);
+  __syncthreads();
+  tile_linear<512, 256, true, ACT_NONE>(bufA, bufB, a.w.s3_w, a.w.s3_b, nullptr, 0);
+  __syncthreads();
+
+  if (!EDIT) {
+    // z (optionally unit-normalised) -> global; wave handles 8 rows
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr;
+      if (m0 + r >= n) continue;
+      f32x4 v = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
+      if (a.unit) {
+        const float nn = sqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
+        v = v / fmaxf(nn, 1e-8f);
+      }
+      *(f32x4*)(a.z + (size_t)(m0 + r) * 256 + lane * 4) = v;
+    }
+    return;
+  } else {
+    const bool simplest = a.flags & ST_F_SIMPLEST;
+    if (!simplest) {
+      tile_linear<256, 128, true, ACT_LRELU>(bufB, bufA, a.w.p1_w, a.w.p1_b, bitsq, 4);
+      __syncthreads();
+      tile_linear<128, 256, true, ACT_NONE>(bufA, bufB, a.w.p2_w, a.w.p2_b, nullptr, 0);
+      __syncthreads();
+    }
+    // ---- scores, loss, dL/dp  (p in bufB[.,0:256]; dP -> bufA[.,0:256]) ----
+    const int np = a.n_pos, nn = a.n_neg, nt = np + nn;
+    const float inv_tau = 1.0f / a.tau;
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr;
+      const int b = min(m0 + r, n - 1);
+      const f32x4 p = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
+      const float pn = fmaxf(sqrtf(wave_sum(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w)), 1e-8f);
+      for (int j = 0; j < nt; ++j) {
+        const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
+        const f32x4 zj = *(const f32x4*)(zp + lane * 4);
+        const float d = wave_sum(p.x * zj.x + p.y * zj.y + p.z * zj.z + p.w * zj.w);
+        if (lane == 0) cosv[r * 32 + j] = d / pn;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // per-lane coefficient g_j = d(-loss_ref)/d cos_j ; loss_ref = what get_contrastive_loss returns
+      float g = 0.0f, lossv = 0.0f;
+      if (a.flags & ST_F_NOT_NLL) {
+        // loss_ref = (sum neg - sum pos) / (np + nn)      (siamese_contrastive.py:424-436)
+        const float c = inv_tau / (float)nt;
+        if (lane < nt) g = lane < np ? c : -c;
+        float sacc = 0.0f;
+        for (int j = 0; j < nt; ++j) sacc += (j < np ? -1.0f : 1.0f) * cosv[r * 32 + j] * inv_tau;
+        lossv = sacc / (float)nt;
+      } else {
+        // loss_i = -log_softmax([pos_i, neg_0..])[0]; loss_ref = mean_i (or min_i with --just_use_one)  (:438-453)
+        float negmax = -INFINITY;
+        for (int k = 0; k < nn; ++k) negmax = fmaxf(negmax, cosv[r * 32 + np + k] * inv_tau);
+        int best_i = 0;
+        float best_l = INFINITY, mean_l = 0.0f;
+        for (int i = 0; i < np; ++i) {
+          const float si = cosv[r * 32 + i] * inv_tau;
+          const float M = fmaxf(si, negmax);
+          float den = expf(si - M);
+          for (int k = 0; k < nn; ++k) den += expf(cosv[r * 32 + np + k] * inv_tau - M);
+          const float li = M + logf(den) - si;
+          mean_l += li;
+          if (li < best_l) { best_l = li; best_i = i; }
+        }
+        const bool one = a.flags & ST_F_JUST_USE_ONE;
+        lossv = one ? best_l : mean_l / (float)np;
+        if (lane < nt) {
+          float cj = 0.0f;  // d loss_ref / d s_lane
+          const float sl = cosv[r * 32 + lane] * inv_tau;
+          for (int i = 0; i < np; ++i) {
+            const float wi = one ? (i == best_i ? 1.0f : 0.0f) : 1.0f / (float)np;
+            if (wi == 0.0f) continue;
+            const float si = cosv[r * 32 + i] * inv_tau;
+            const float M = fmaxf(si, negmax);
+            float den = expf(si - M);
+            for (int k = 0; k < nn; ++k) den += expf(cosv[r * 32 + np + k] * inv_tau - M);
+            if (lane < np) {
+              if (i == lane) cj += wi * (expf(si - M) / den - 1.0f);
+            } else {
+              cj += wi * expf(sl - M) / den;
+            }
+          }
+          g = -cj * inv_tau;
+        }
+      }
+      if (lane < 32) coef[r * 32 + lane] = lane < nt ? g : 0.0f;
+      __builtin_amdgcn_wave_barrier();
+      f32x4 gs = {0, 0, 0, 0};
+      float gc = 0.0f;
+      for (int j = 0; j < nt; ++j) {
+        const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
+        const f32x4 zj = *(const f32x4*)(zp + lane * 4);
+        const float gj = coef[r * 32 + j];
+        gs += gj * zj;
+        gc += gj * cosv[r * 32 + j];
+      }
+      const f32x4 dp = gs / pn - (gc / (pn * pn)) * p;
+      *(f32x4*)(bufA + r * SC_LD + lane * 4) = dp;
+      if (lane == 0 && a.loss_out && m0 + r < n) a.loss_out[m0 + r] = lossv;
+    }
+    __syncthreads();
+    // ---- backward to the latent ----
+    if (!simplest) {
+      tile_linear<256, 128, false, BWD_LRELU>(bufA, bufB, a.w.p2_wt, nullptr, bitsq, 4);
+      __syncthreads();
+      tile_linear<128, 256, false, BWD_NONE>(bufB, bufA, a.w.p1_wt, nullptr, nullptr, 0);
+      __syncthreads();
+    }
+    tile_linear<256, 512, false, BWD_RELU>(bufA, bufB, a.w.s3_wt, nullptr, bits2, 16);
+    __syncthreads();
+    tile_linear<512, 512, false, BWD_RELU>(bufB, bufA, a.w.s2_wt, nullptr, bits1, 16);
+    __syncthreads();
+    tile_linear<512, 256, false, BWD_NONE>(bufA, bufB, a.w.s1_wt, nullptr, nullptr, 0);
+    __syncthreads();
+    // ---- Adam (torch.optim.Adam single-tensor path, betas (0.9, 0.999), eps 1e-8) ----
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr;
+      const int b = m0 + r;
+      if (b >= n) continue;
+      const f32x4 g = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
+      if (a.grad_out) *(f32x4*)(a.grad_out + (size_t)b * 256 + lane * 4) = g;
+      if (a.active && !a.active[b]) continue;
+      const int t = a.step[b] + 1;
+      const double bc1 = 1.0 - pow(0.9, (double)t);
+      const double bc2 = 1.0 - pow(0.999, (double)t);
+      const float step_size = (float)((double)a.lr[b] / bc1);
+      const float bc2s = (float)sqrt(bc2);
+      f32x4 m = *(const f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4);
+      f32x4 v = *(const f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4);
+      f32x4 x = *(const f32x4*)(a.latent + (size_t)b * 256 + lane * 4);
+      m = m + 0.1f * (g - m);
+      v = v * 0.999f + (0.001f * g) * g;
+      f32x4 den;
+      den.x = sqrtf(v.x) / bc2s + 1e-8f;
+      den.y = sqrtf(v.y) / bc2s + 1e-8f;
+      den.z = sqrtf(v.z) / bc2s + 1e-8f;
+      den.w = sqrtf(v.w) / bc2s + 1e-8f;
+      x = x - step_size * (m / den);
+      *(f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4) = m;
+      *(f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4) = v;
+      *(f32x4*)(a.latent + (size_t)b * 256 + lane * 4) = x;
+      if (lane == 0) a.step[b] = t;
+    }
+  }
+}
+
+#define SC_LDS_BYTES ((2 * SC_BUF + 32 * 16 * 2 + 32 * 4 + 32 * 32 * 2) * 4)
+
+static int check_scorer(const StScorerWeights* w) {
+  ST_CHECK_ARG(w != nullptr, "scorer weights struct is NULL");
+  ST_CHECK_ARG(w->s1_w && w->s1_wt && w->s1_b && w->s2_w && w->s2_wt && w->s2_b && w->s3_w && w->s3_wt && w->s3_b,
+               "NULL SiameseNet weight pointer");
+  return ST_OK;
+}
+
+template <bool EDIT>
+static int launch_scorer(const ScorerArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)scorer_kernel<EDIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SC_LDS_BYTES));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(scorer_kernel<EDIT>, dim3((a.n + SC_ROWS - 1) / SC_ROWS), dim3(256), SC_LDS_BYTES, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+extern "C" int st_scorer_embed(const StScorerWeights* w, const float* x, float* z, int n, int unit, void* stream) {
+  int rc = check_scorer(w);
+  if (rc) return rc;
+  ST_CHECK_ARG(n >= 0, "n=%d", n);
+  if (n == 0) return ST_OK;
+  ST_CHECK_ARG(x && z, "NULL buffer");
+  ScorerArgs a = {};
+  a.w = *w; a.x = x; a.z = z; a.n = n; a.unit = unit;
+  return launch_scorer<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int st_scorer_edit_step(const StScorerWeights* w, float* latent, float* adam_m, float* adam_v,
+                                   const float* like_z, const float* unlike_z, int n_pos, int n_neg, const float* lr,
+                                   int* step, const uint8_t* active, int B, float tau, int flags, float* loss_out,
+                                   float* grad_out, void* stream) {
+  int rc = check_scorer(w);
+  if (rc) return rc;
+  ST_CHECK_ARG(B >= 0, "B=%d", B);
+  if (B == 0) return ST_OK;
+  ST_CHECK_ARG(latent && adam_m && adam_v && lr && step, "NULL buffer");
+  ST_CHECK_ARG(n_pos >= 0 && n_pos <= ST_MAX_REFS && n_neg >= 0 && n_neg <= ST_MAX_REFS, "n_pos=%d n_neg=%d (max %d each)",
+               n_pos, n_neg, ST_MAX_REFS);
+  ST_CHECK_ARG(n_pos + n_neg > 0, "need at least one like or unlike sentence");
+  ST_CHECK_ARG((n_pos == 0 || like_z) && (n_neg == 0 || unlike_z), "NULL like_z/unlike_z");
+  ST_CHECK_ARG((flags & ST_F_NOT_NLL) || n_pos > 0, "the NLL objective needs n_pos > 0");
+  ST_CHECK_ARG(tau > 0.0f, "tau=%g", (double)tau);
+  if (!(flags & ST_F_SIMPLEST))
+    ST_CHECK_ARG(w->p1_w && w->p1_wt && w->p1_b && w->p2_w && w->p2_wt && w->p2_b, "NULL Predictor weight pointer");
+  ScorerArgs a = {};
+  a.w = *w; a.n = B; a.latent = latent; a.adam_m = adam_m; a.adam_v = adam_v; a.like_z = like_z; a.unlike_z = unlike_z;
+  a.n_pos = n_pos; a.n_neg = n_neg; a.lr = lr; a.step = step; a.active = active; a.tau = tau; a.flags = flags;
+  a.loss_out = loss_out; a.grad_out = grad_out;
+  return launch_scorer<true>(a, (hipStream_t)stream);
+}
