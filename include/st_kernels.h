@@ -154,6 +154,28 @@ int st_simloss_bwd(const float* ori, const float* like, int Bq, int Bk, float ta
                    size_t scratch_bytes, void* stream);
 size_t st_simloss_scratch_bytes(int Bq, int Bk);
 
+/* ---------------------------------------------------------------------------------------------
+ * (6) Encoder -> latent, batched and length-packed (EncoderDecoder.forward's encoder half /
+ * get_latent, model.py:229-240, :253-257; Encoder :137-163).  latent[s] = sum over the sentence's
+ * non-pad tokens of sigmoid(encoder(x)).  The reference's unused teacher-forced decode inside
+ * forward() (model.py:248-249) is not computed.
+ *   tokens/tok_pos [n_rows]: packed non-pad token ids and their position in the sentence
+ *   sent_off [n_sent+1]: first row of each sentence (sent_off[n_sent] = n_rows); max_sent_len <= 64 */
+typedef struct StEncLayer {
+  const float *ln0_a, *ln0_b, *wqkv, *bqkv, *wo, *bo, *ln1_a, *ln1_b, *w1, *b1, *w2, *b2;
+} StEncLayer;
+typedef struct StEncoderWeights {
+  int32_t d_model, n_heads, d_ff, n_layers, vocab, pe_rows;
+  const float* emb;                    /* src_embed.0.lut.weight [V,256] (shared with tgt)      */
+  const float* pe;                     /* src_embed.1.pe                                        */
+  const float *lnf_a, *lnf_b;          /* encoder.norm                                          */
+  StEncLayer layer[ST_MAX_LAYERS];
+} StEncoderWeights;
+size_t st_encode_workspace_bytes(const StEncoderWeights* w, int n_rows, int n_sent);
+int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens, const int32_t* tok_pos,
+                     const int32_t* sent_off, int n_rows, int n_sent, int max_sent_len, float* latent,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

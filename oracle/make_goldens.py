@@ -1,0 +1,219 @@
+"""Fixture generator (build container only; needs /root/reference).  Runs the UNMODIFIED reference
+functions on the surrogate AE checkpoint + the shipped SiameseNet/Predictor weights and records
+golden vectors under tests/golden/.
+
+What runs: siamese_contrastive.attack_contrastive (siamese_contrastive.py:672-743) itself, with
+  * create_train_data_loader_contrastive wrapped so the three loaders hold a SUBSET of the 1000 test
+    sentences (the function walks loader.num_batch sentences; the full set takes ~3 h on 8 cores),
+  * print_and_log wrapped to capture the log lines,
+  * get_contrastive_loss / ae_model.greedy_decode / ae_model.forward wrapped to RECORD their inputs
+    and outputs (latent before/after each Adam step, gradient, loss, decoded ids, top-2 logit gap).
+No arithmetic is restated here: every number comes out of the reference's own code.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_harness  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def load_ae(ref_model, args, ckpt):
+    from safetensors.torch import load_file
+    sd = load_file(ckpt)
+    ae = ref_model.make_model(args.vocab_size, 2, 256, 256, 1024)
+    full = ae.state_dict()
+    for k in full:
+        if k.endswith(".pe"):
+            continue
+        src = "src_embed.0.lut.weight" if k == "tgt_embed.0.lut.weight" else k
+        full[k] = sd[src]
+    ae.load_state_dict(full)
+    ae.eval()
+    return ae
+
+
+def run_attack(subset, flags, ckpt, tag, threads):
+    torch.set_num_threads(threads)
+    ref_model, ref_data, ref_sc = ref_harness.import_reference()
+    args = ref_harness.make_args("yelp", **flags)
+    ae = load_ae(ref_model, args, ckpt)
+    siamese, predictor = ref_sc.SiameseNet(256), ref_sc.Predictor(256)
+    ref_sc.load_siamese(siamese, predictor, args)
+
+    lines = []
+    ref_sc.print_and_log = lambda s: lines.append(s)
+
+    orig_create = ref_sc.create_train_data_loader_contrastive
+
+    def create_subset(*a, **k):
+        loaders = orig_create(*a, **k)
+        for ld in loaders:
+            if ld.src_batches == []:
+                continue
+            for name in ("src_batches", "tgt_batches", "tgt_y_batches", "src_mask_batches", "tgt_mask_batches", "ntokens_batches"):
+                full = getattr(ld, name)
+                setattr(ld, name, [full[i] for i in subset])
+            ld.num_batch = len(subset)
+        return loaders
+
+    ref_sc.create_train_data_loader_contrastive = create_subset
+
+    rec = dict(enc_src=[], enc_latent=[], sent=[])
+    cur = {}
+
+    orig_forward = ae.forward
+
+    def forward(src, tgt, src_mask, tgt_mask):
+        latent, prob = orig_forward(src, tgt, src_mask, tgt_mask)
+        if src is not None:
+            rec["enc_src"].append(src.numpy().copy())
+            rec["enc_latent"].append(latent.detach().numpy().copy())
+        return latent, prob
+
+    ae.forward = forward
+
+    gaps_step = []
+
+    def gen_hook(mod, inp, out):
+        if out.dim() == 2:
+            top = out.detach().topk(2, dim=-1).values
+            gaps_step.append((top[:, 0] - top[:, 1]).numpy().copy())
+
+    ae.generator.register_forward_hook(gen_hook)
+
+    orig_decode = ae.greedy_decode
+    decodes = []
+
+    def greedy_decode(latent, max_len, start_id):
+        gaps_step.clear()
+        ys = orig_decode(latent, max_len, start_id)
+        if latent is not None:
+            decodes.append(dict(latent=latent.detach().numpy().copy(), ids=ys.numpy().copy(),
+                                gap=np.stack(gaps_step, 1).copy(),
+                                grad=None if latent.grad is None else latent.grad.numpy().copy()))
+        return ys
+
+    ae.greedy_decode = greedy_decode
+
+    orig_loss = ref_sc.get_contrastive_loss
+    losses = []
+
+    def get_loss(*a, **k):
+        out = orig_loss(*a, **k)
+        losses.append(float(out[0].item()))
+        return out
+
+    ref_sc.get_contrastive_loss = get_loss
+
+    orig_attack_one = ref_sc.contrastive_attack_one
+    per_sentence = []
+
+    def attack_one(sn, pn, aem, ori_latent, like_latent, unlike_latent, a):
+        decodes.clear()
+        losses.clear()
+        orig_attack_one(sn, pn, aem, ori_latent, like_latent, unlike_latent, a)
+        per_sentence.append(dict(
+            like_latent=None if like_latent is None else like_latent.numpy().copy(),
+            unlike_latent=None if unlike_latent is None else unlike_latent.numpy().copy(),
+            decodes=[dict(d) for d in decodes], losses=list(losses), lr=a.victim_lr))
+
+    ref_sc.contrastive_attack_one = attack_one
+
+    t0 = time.time()
+    ref_sc.attack_contrastive(siamese, predictor, ae, args)
+    dt = time.time() - t0
+    print("[%s] reference attack_contrastive on %d sentences: %.1f s (%.2f s/sentence, %d threads)" %
+          (tag, len(subset), dt, dt / len(subset), threads), flush=True)
+
+    S, I, T = len(subset), args.attack_max_iter, args.max_sequence_length - 1
+    n_iter = np.zeros(S, np.int32)
+    init_latent = np.zeros((S, 256), np.float32)
+    init_ids = np.zeros((S, T), np.int32)
+    init_gap = np.zeros((S, T), np.float32)
+    lat = np.zeros((S, I, 256), np.float32)
+    grad = np.zeros((S, I, 256), np.float32)
+    ids = np.zeros((S, I, T), np.int32)
+    gap = np.zeros((S, I, T), np.float32)
+    loss = np.zeros((S, I), np.float32)
+    kp = per_sentence[0]["like_latent"].shape[0] if per_sentence[0]["like_latent"] is not None else 0
+    kn = per_sentence[0]["unlike_latent"].shape[0] if per_sentence[0]["unlike_latent"] is not None else 0
+    like = np.zeros((S, kp, 256), np.float32)
+    unlike = np.zeros((S, kn, 256), np.float32)
+    lr = np.zeros(S, np.float32)
+    for s, ps in enumerate(per_sentence):
+        d0 = ps["decodes"][0]
+        init_latent[s], init_ids[s], init_gap[s] = d0["latent"][0], d0["ids"][0], d0["gap"][0]
+        n_iter[s] = len(ps["decodes"]) - 1
+        for it, d in enumerate(ps["decodes"][1:]):
+            lat[s, it], ids[s, it], gap[s, it], grad[s, it] = d["latent"][0], d["ids"][0], d["gap"][0], d["grad"][0]
+            loss[s, it] = ps["losses"][it]
+        if kp:
+            like[s] = ps["like_latent"][:, 0]
+        if kn:
+            unlike[s] = ps["unlike_latent"][:, 0]
+        lr[s] = ps["lr"]
+    # encoder goldens: every ae_model.forward call in order (1 + kp + kn per sentence)
+    Lmax = max(x.shape[1] for x in rec["enc_src"])
+    enc_src = np.zeros((len(rec["enc_src"]), Lmax), np.int32)
+    for i, x in enumerate(rec["enc_src"]):
+        enc_src[i, : x.shape[1]] = x[0]
+    enc_latent = np.concatenate(rec["enc_latent"], 0).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "attack_%s.npz" % tag), subset=np.asarray(subset, np.int32), n_iter=n_iter,
+                        init_latent=init_latent, init_ids=init_ids, init_gap=init_gap, latent=lat, grad=grad, ids=ids,
+                        gap=gap, loss=loss, like_latent=like, unlike_latent=unlike, lr=lr, enc_src=enc_src,
+                        enc_latent=enc_latent, ref_seconds=np.float32(dt), ref_threads=np.int32(threads))
+    with open(os.path.join(GOLD, "attack_%s_log.txt" % tag), "w") as f:
+        for ln in lines:
+            f.write("INFO:siamese_contrastive.py:print_and_log:1592 - " + ln + "\n")
+    return dt
+
+
+def run_simloss():
+    """The B x B in-batch InfoNCE block of train_ae_model_constraint (siamese_contrastive.py:1060-1069),
+    same torch calls, B = 128 (main.py:67), 3 views, with autograd gradients."""
+    import torch.nn.functional as F
+    torch.manual_seed(7)
+    B, tau = 128, 0.1
+    ori = (torch.rand(B, 256) * 10).requires_grad_(True)
+    like = (torch.rand(3, B, 256) * 10).requires_grad_(True)
+    crit = torch.nn.NLLLoss()
+    losses, per_row = [], []
+    for i in range(3):
+        sim = F.cosine_similarity(ori.unsqueeze(1), like[i], dim=-1) / tau
+        targets = torch.tensor(list(range(B)))
+        sim_softmax = F.log_softmax(sim, dim=-1)
+        losses.append(crit(sim_softmax, targets))
+        per_row.append(-sim_softmax[torch.arange(B), targets].detach().numpy())
+    total = sum(losses) / len(losses)
+    total.backward()
+    np.savez_compressed(os.path.join(GOLD, "simloss_b128.npz"), ori=ori.detach().numpy(), like=like.detach().numpy(),
+                        loss_rows=np.stack(per_row), loss=np.float32(total.item()), d_ori=ori.grad.numpy(),
+                        d_like=like.grad.numpy(), tau=np.float32(tau))
+    print("simloss golden written, loss", total.item())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="main")
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--n", type=int, default=32, help="sentences per label for the main run")
+    a = ap.parse_args()
+    ckpt = os.path.join(GOLD, "surrogate_ae_yelp.safetensors")
+    if a.what == "simloss":
+        run_simloss()
+    elif a.what == "main":
+        subset = list(range(a.n)) + list(range(500, 500 + a.n))
+        run_attack(subset, dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "notnll", a.threads)
+    elif a.what == "variants":
+        sub = [0, 1, 2, 500, 501, 502]
+        run_attack(sub, dict(), ckpt, "nll", a.threads)
+        run_attack(sub, dict(just_use_one=True), ckpt, "nll_one", a.threads)
+        run_attack(sub, dict(not_nll=True, simplest_siamese=True, pos_victim_lr=0.2, neg_victim_lr=0.3), ckpt, "simplest", a.threads)
+        run_attack(sub, dict(not_nll=True, pos_num=3, neg_num=5, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "p3n5", a.threads)

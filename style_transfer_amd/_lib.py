@@ -1,0 +1,95 @@
+"""ctypes binding of libst_kernels.so (include/st_kernels.h).  Fails loudly when the HIP library is
+missing: there is no CPU or PyTorch fallback for the product path."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libst_kernels.so")
+
+ST_MAX_LAYERS = 4
+ST_MAX_REFS = 16
+ST_ARGMAX_SPLITS = 4
+ST_F_NOT_NLL, ST_F_SIMPLEST, ST_F_JUST_USE_ONE = 1, 2, 4
+ST_DEC_EARLY_EXIT = 1
+
+fp = C.c_void_p  # device pointers travel as integers
+
+
+class StScorerWeights(C.Structure):
+    _fields_ = [(n, fp) for n in (
+        "s1_w", "s1_wt", "s1_b", "s2_w", "s2_wt", "s2_b", "s3_w", "s3_wt", "s3_b",
+        "p1_w", "p1_wt", "p1_b", "p2_w", "p2_wt", "p2_b")]
+
+
+class StDecLayer(C.Structure):
+    _fields_ = [(n, fp) for n in (
+        "ln0_a", "ln0_b", "wqkv", "bqkv", "wo", "bo", "xv_w", "xv_b", "xo_w", "xo_b",
+        "ln2_a", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
+class StDecoderWeights(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
+                ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
+                ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp), ("gen_w", fp), ("gen_b", fp),
+                ("layer", StDecLayer * ST_MAX_LAYERS)]
+
+
+class StEncLayer(C.Structure):
+    _fields_ = [(n, fp) for n in (
+        "ln0_a", "ln0_b", "wqkv", "bqkv", "wo", "bo", "ln1_a", "ln1_b", "w1", "b1", "w2", "b2")]
+
+
+class StEncoderWeights(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
+                ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
+                ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp),
+                ("layer", StEncLayer * ST_MAX_LAYERS)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "st_abi_version": (C.c_int, []),
+    "st_last_error": (C.c_char_p, []),
+    "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
+    "st_scorer_edit_step": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
+                                      C.c_int, C.c_float, C.c_int, fp, fp, fp]),
+    "st_decode_workspace_bytes": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int, C.c_int]),
+    "st_decode_greedy": (C.c_int, [C.POINTER(StDecoderWeights), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, fp, fp, fp, C.c_size_t, C.POINTER(C.c_int), fp]),
+    "st_gemm_argmax": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp]),
+    "st_accept_changes": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp,
+                                    fp, fp, fp, fp]),
+    "st_simloss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "st_simloss_fwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, C.c_size_t, fp]),
+    "st_simloss_bwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, fp, fp, C.c_size_t, fp]),
+    "st_encode_workspace_bytes": (C.c_size_t, [C.POINTER(StEncoderWeights), C.c_int, C.c_int]),
+    "st_encode_latent": (C.c_int, [C.POINTER(StEncoderWeights), fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
+}
+
+_lib = None
+
+
+class StError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it is missing — build it with
+    `python -m style_transfer_amd.build` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StError("HIP extension %s is missing; run `python -m style_transfer_amd.build`. "
+                          "There is no CPU fallback for the product path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise StError("%s failed (%d): %s" % (what, rc, lib().st_last_error().decode()))

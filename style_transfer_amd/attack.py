@@ -1,0 +1,220 @@
+"""The gradient-guided attack driver, batch-first (replaces attack_contrastive +
+contrastive_attack_one, /root/reference/method/yelp/siamese_contrastive.py:672-839).
+
+The reference walks the 1000 test sentences one at a time; every sentence is independent (nets in
+eval mode, fresh Adam per sentence, :689-691, :780), so here a batch of B sentences moves through
+the same steps together, each with its own Adam state, change counter and stop flag:
+
+  encode ori/like/unlike      -> st_encode_latent    (one packed launch sequence for all 21*B sentences)
+  like_z / unlike_z           -> st_scorer_embed     (once; the reference recomputes them every iteration)
+  [Rec/Sim/Ref log decodes]   -> st_decode_greedy    (optional, only needed for the log lines)
+  for it in range(max_iter):
+      score, backward, Adam   -> st_scorer_edit_step (all B rows, inactive rows masked)
+      greedy decode           -> st_decode_greedy    (live rows only, compacted)
+      text change bookkeeping -> st_accept_changes
+"""
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import ops
+from .data import AttackSet, id2text_sentence, pack_sentences
+from .logfmt import headline
+
+
+@dataclass
+class AttackConfig:
+    """The attack-relevant flags of main.py:35-126 (same names and defaults)."""
+    id_pad: int = 0
+    id_unk: int = 1
+    id_bos: int = 2
+    id_eos: int = 3
+    max_sequence_length: int = 60
+    tau: float = 0.1
+    victim_optimizer: str = "Adam"
+    victim_lr: float = 0.25
+    attack_max_iter: int = 18
+    attack_max_change: int = 7
+    simplest_siamese: bool = False
+    just_use_one: bool = False
+    not_nll: bool = False
+    retext: bool = False
+    dance: bool = False
+    pos_victim_lr: float = 0.25
+    neg_victim_lr: float = 0.25
+    # build-side knobs (no reference counterpart)
+    early_exit: bool = True        # stop decoding a sentence at its first EOS/PAD (output-equivalent)
+    sync_every: int = 1
+    log_decodes: bool = True       # the 1+10+10 decodes behind the Rec:/Sim:/Ref: log lines
+    want_gap: bool = False
+    want_trace: bool = False       # keep latents / grads / losses per iteration (parity tests)
+
+    @classmethod
+    def from_namespace(cls, ns, **over):
+        kw = {k: getattr(ns, k) for k in cls.__dataclass_fields__ if hasattr(ns, k)}
+        kw.update(over)
+        return cls(**kw)
+
+
+@dataclass
+class AttackResult:
+    """Per-sentence records, all numpy on the host; enough to write the reference's log."""
+    n_iter: np.ndarray            # [S] iterations run (<= max_iter)
+    init_ids: np.ndarray          # [S,T] decode of the un-edited latent (the 'Rec:' line)
+    iter_ids: np.ndarray          # [S,I,T] accepted text after each iteration
+    changed: np.ndarray           # [S,I] 1 where a 'Change.k' line precedes 'iteration.it'
+    like_ids: np.ndarray = None   # [S,K+,T] 'Sim{i}:' decodes (log_decodes)
+    unlike_ids: np.ndarray = None
+    final_latent: np.ndarray = None
+    trace: dict = field(default_factory=dict)
+    timing: dict = field(default_factory=dict)
+
+
+class AttackRunner:
+    def __init__(self, ae, scorer, cfg: AttackConfig, device):
+        if cfg.victim_optimizer != "Adam":
+            raise NotImplementedError("--victim_optimizer %s: only Adam has a kernel (the reference default, main.py:100)" % cfg.victim_optimizer)
+        if cfg.retext:
+            raise NotImplementedError("--retext is not implemented yet (SURVEY.md §8f rank 2)")
+        self.ae, self.scorer, self.cfg, self.device = ae, scorer, cfg, device
+        self.ws = ops.DecodeWorkspace(device)
+        self.canon = None
+
+    def set_vocab(self, id_to_word):
+        from .data import canonical_ids
+        c = canonical_ids(id_to_word)
+        self.canon = None if c is None else torch.from_numpy(c).to(self.device)
+
+    # -- pieces -----------------------------------------------------------------------------------
+    def encode(self, sents):
+        tokens, tok_pos, sent_off, max_len = pack_sentences(sents)
+        dev = self.device
+        t = torch.from_numpy(tokens).to(dev)
+        p = torch.from_numpy(tok_pos).to(dev)
+        o = torch.from_numpy(sent_off).to(dev)
+        return ops.encode_latent(self.ae, t, p, o, len(sents), max_len, ws=self.ws)
+
+    def decode(self, latent, want_gap=False):
+        c = self.cfg
+        return ops.greedy_decode(self.ae, latent, c.max_sequence_length, c.id_bos, c.id_eos, c.id_pad,
+                                 early_exit=c.early_exit, sync_every=c.sync_every, want_gap=want_gap, ws=self.ws)
+
+    # -- one batch --------------------------------------------------------------------------------
+    def run_batch(self, batch: AttackSet, global_index) -> AttackResult:
+        """global_index [B]: position of each sentence in the full run (lr switch at 500, :740)."""
+        c, dev = self.cfg, self.device
+        B, kp, kn = len(batch), batch.n_pos, batch.n_neg
+        T = c.max_sequence_length - 1
+        I = 2 if c.dance else c.attack_max_iter
+        tm = {}
+        t0 = time.perf_counter()
+        sents = list(batch.origin) + [s for grp in batch.like for s in grp] + [s for grp in batch.unlike for s in grp]
+        lat_all = self.encode(sents)
+        ori = lat_all[:B].clone()
+        like_lat = lat_all[B:B + B * kp]
+        unlike_lat = lat_all[B + B * kp:]
+        like_z = ops.scorer_embed(self.scorer, like_lat).view(B, kp, 256) if kp else None
+        unlike_z = ops.scorer_embed(self.scorer, unlike_lat).view(B, kn, 256) if kn else None
+        res = AttackResult(None, None, None, None)
+        if c.log_decodes:
+            all_ids, _, _ = self.decode(lat_all)
+            init_ids = all_ids[:B].clone()
+            res.like_ids = all_ids[B:B + B * kp].view(B, kp, T).cpu().numpy() if kp else None
+            res.unlike_ids = all_ids[B + B * kp:].view(B, kn, T).cpu().numpy() if kn else None
+            init_gap = None
+        else:
+            init_ids, init_gap, _ = self.decode(ori, want_gap=c.want_gap)
+        gidx = torch.as_tensor(np.asarray(global_index), device=dev)
+        lr = torch.where(gidx < 500, torch.tensor(c.pos_victim_lr, device=dev), torch.tensor(c.neg_victim_lr, device=dev)).float().contiguous()
+        m = torch.zeros(B, 256, device=dev)
+        v = torch.zeros(B, 256, device=dev)
+        step = torch.zeros(B, dtype=torch.int32, device=dev)
+        active = torch.ones(B, dtype=torch.uint8, device=dev)
+        n_changes = torch.zeros(B, dtype=torch.int32, device=dev)
+        changed = torch.zeros(I, B, dtype=torch.uint8, device=dev)
+        was_active = torch.zeros(I, B, dtype=torch.uint8, device=dev)
+        acc_ids = init_ids.clone()
+        iter_ids = torch.zeros(I, B, T, dtype=torch.int32, device=dev)
+        new_ids = torch.zeros(B, T, dtype=torch.int32, device=dev)
+        tr = {k: [] for k in ("latent", "grad", "loss", "ids", "gap")} if c.want_trace else None
+        max_change = (1 << 30) if c.dance else c.attack_max_change
+        torch.cuda.synchronize(dev)
+        tm["setup_s"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        n_units = 0
+        for it in range(I):
+            live = torch.nonzero(active, as_tuple=False).flatten()
+            n_live = int(live.numel())
+            if n_live == 0:
+                break
+            n_units += n_live
+            was_active[it] = active
+            loss, grad = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, active, tau=c.tau,
+                                              not_nll=c.not_nll, simplest=c.simplest_siamese,
+                                              just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
+                                              want_grad=c.want_trace)
+            if n_live == B:
+                ids, gap, _ = self.decode(ori, want_gap=c.want_gap or c.want_trace)
+                new_ids.copy_(ids)
+            else:
+                ids, gap, _ = self.decode(ori.index_select(0, live).contiguous(), want_gap=c.want_gap or c.want_trace)
+                new_ids.index_copy_(0, live, ids)
+            ops.accept_changes(new_ids, acc_ids, self.ae.vocab, n_changes, changed[it], active, max_change=max_change,
+                               unk=c.id_unk, eos=c.id_eos, pad=c.id_pad, canon=self.canon, rec_ids=iter_ids[it])
+            if tr is not None:
+                g_full = torch.zeros(B, T, device=dev)
+                g_full.index_copy_(0, live, gap) if n_live != B else g_full.copy_(gap)
+                for k, t in (("latent", ori), ("grad", grad), ("loss", loss), ("ids", new_ids), ("gap", g_full)):
+                    tr[k].append(t.detach().cpu().numpy().copy())
+        torch.cuda.synchronize(dev)
+        tm["loop_s"] = time.perf_counter() - t1
+        tm["units"] = n_units
+        res.n_iter = was_active.sum(0).cpu().numpy().astype(np.int32)
+        res.init_ids = init_ids.cpu().numpy()
+        res.iter_ids = iter_ids.permute(1, 0, 2).contiguous().cpu().numpy()
+        res.changed = changed.t().contiguous().cpu().numpy()
+        res.final_latent = ori.cpu().numpy()
+        if tr is not None:
+            res.trace = {k: np.stack(vv, 1) if vv else None for k, vv in tr.items()}
+            res.trace["init_gap"] = None if init_gap is None else init_gap.cpu().numpy()
+            res.trace["init_latent"] = lat_all[:B].cpu().numpy()
+            res.trace["like_latent"] = like_lat.view(B, kp, 256).cpu().numpy() if kp else None
+            res.trace["unlike_latent"] = unlike_lat.view(B, kn, 256).cpu().numpy() if kn else None
+        res.timing = tm
+        return res
+
+
+def concat_results(parts):
+    cat = lambda xs: None if any(x is None for x in xs) else np.concatenate(xs, 0)
+    r = AttackResult(cat([p.n_iter for p in parts]), cat([p.init_ids for p in parts]), cat([p.iter_ids for p in parts]),
+                     cat([p.changed for p in parts]), cat([p.like_ids for p in parts]), cat([p.unlike_ids for p in parts]),
+                     cat([p.final_latent for p in parts]))
+    r.timing = {k: sum(p.timing.get(k, 0) for p in parts) for k in ("setup_s", "loop_s", "units")}
+    if parts and parts[0].trace:
+        r.trace = {k: cat([p.trace[k] for p in parts]) for k in parts[0].trace}
+    return r
+
+
+def write_attack_log(log, data: AttackSet, res: AttackResult, id_to_word, first_index=0, dance=False):
+    """The per-sentence block of the reference's log, in global order (SURVEY.md Appendix A item 8;
+    siamese_contrastive.py:702-732, :789, :825-836)."""
+    for s in range(len(data)):
+        log(headline("Sentence Pair.{}".format(first_index + s)))
+        log("Src: " + id2text_sentence(data.origin[s], id_to_word))
+        log("Rec: " + id2text_sentence(res.init_ids[s], id_to_word))
+        if res.like_ids is not None:
+            for i in range(res.like_ids.shape[1]):
+                log("Sim{}: ".format(i) + id2text_sentence(res.like_ids[s, i], id_to_word))
+        if res.unlike_ids is not None:
+            for i in range(res.unlike_ids.shape[1]):
+                log("Ref{}: ".format(i) + id2text_sentence(res.unlike_ids[s, i], id_to_word))
+        log(headline("", note_token="-"))
+        k = 0
+        for it in range(int(res.n_iter[s])):
+            text = id2text_sentence(res.iter_ids[s, it], id_to_word)
+            if res.changed[s, it] and not dance:
+                log("Change.{}, {}".format(k, text))
+                k += 1
+            log("iteration.{}, {}".format(it, text))

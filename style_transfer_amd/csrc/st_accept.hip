@@ -1,0 +1,61 @@
+// Text-change detection on token ids (replaces id2text_sentence + the string compare and the
+// Change/iteration bookkeeping of contrastive_attack_one,
+// /root/reference/method/yelp/data.py:43-52 and siamese_contrastive.py:816-839).
+//
+// Two decodes give the same TEXT iff their id prefixes up to the first EOS(3)/PAD(0) agree after
+// (a) ids >= vocab -> UNK and (b) mapping ids that spell the same word to one canonical id.
+// One thread per sentence; rows are <= 64 ids.
+#include "st_common.h"
+
+__device__ __forceinline__ int canon_id(int t, int vocab, int unk, const int32_t* canon) {
+  if (t >= vocab || t < 0) t = unk;
+  return canon ? canon[t] : t;
+}
+
+__global__ __launch_bounds__(256) void accept_kernel(const int32_t* __restrict__ new_ids, int32_t* __restrict__ acc_ids,
+                                                     int T, int B, int vocab, int unk, int eos, int pad,
+                                                     const int32_t* __restrict__ canon, int max_change,
+                                                     int32_t* __restrict__ n_changes, uint8_t* __restrict__ changed,
+                                                     uint8_t* __restrict__ active, int32_t* __restrict__ rec_ids) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  const bool live = active[s] != 0;
+  const int32_t* nw = new_ids + (size_t)s * T;
+  int32_t* ac = acc_ids + (size_t)s * T;
+  bool diff = false;
+  if (live) {
+    for (int i = 0; i < T; ++i) {
+      const int a = nw[i], b = ac[i];
+      const bool ea = (a == eos || a == pad), eb = (b == eos || b == pad);
+      if (ea || eb) {
+        diff = ea != eb;
+        break;
+      }
+      if (canon_id(a, vocab, unk, canon) != canon_id(b, vocab, unk, canon)) {
+        diff = true;
+        break;
+      }
+    }
+    if (diff) {
+      for (int i = 0; i < T; ++i) ac[i] = nw[i];
+      const int k = n_changes[s] + 1;
+      n_changes[s] = k;
+      if (k >= max_change) active[s] = 0;
+    }
+  }
+  changed[s] = diff ? 1 : 0;
+  if (rec_ids && live)
+    for (int i = 0; i < T; ++i) rec_ids[(size_t)s * T + i] = ac[i];
+}
+
+extern "C" int st_accept_changes(const int32_t* new_ids, int32_t* acc_ids, int T, int B, int vocab, int unk, int eos,
+                                 int pad, const int32_t* canon, int max_change, int32_t* n_changes, uint8_t* changed,
+                                 uint8_t* active, int32_t* rec_ids, void* stream) {
+  ST_CHECK_ARG(B >= 0 && T >= 1, "B=%d T=%d", B, T);
+  if (B == 0) return ST_OK;
+  ST_CHECK_ARG(new_ids && acc_ids && n_changes && changed && active, "NULL buffer");
+  hipLaunchKernelGGL(accept_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, new_ids, acc_ids, T, B,
+                     vocab, unk, eos, pad, canon, max_change, n_changes, changed, active, rec_ids);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}

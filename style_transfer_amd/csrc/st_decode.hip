@@ -129,41 +129,6 @@ __global__ __launch_bounds__(256) void argmax_merge_kernel(const float4* __restr
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
-static int launch_panel(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)panel_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               ST_PANEL_LDS));
-    attr_done = true;
-  }
-  if (n_bound <= 0) return ST_OK;
-  dim3 grid((n_bound + 63) / 64, splits);
-  hipLaunchKernelGGL(panel_gemm_kernel<EPI>, grid, dim3(512), ST_PANEL_LDS, st, a);
-  ST_LAUNCH_CHECK();
-  return ST_OK;
-}
-template <int EPI>
-static int launch_kloop(const GemmArgs& a, int n_bound, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)kloop_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               ST_KLOOP_LDS));
-    attr_done = true;
-  }
-  if (n_bound <= 0) return ST_OK;
-  dim3 grid((n_bound + 127) / 128, (a.N + 127) / 128);
-  hipLaunchKernelGGL(kloop_gemm_kernel<EPI>, grid, dim3(256), ST_KLOOP_LDS, st, a);
-  ST_LAUNCH_CHECK();
-  return ST_OK;
-}
-
-#define ST_TRY(x)            \
-  do {                       \
-    int rc_ = (x);           \
-    if (rc_ != ST_OK) return rc_; \
-  } while (0)
-
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct DecodeWs {

@@ -1,0 +1,142 @@
+// Batched, length-packed Transformer encoder -> latent (replaces EncoderDecoder.forward's encoder
+// half / get_latent, /root/reference/method/yelp/model.py:229-240, :253-257, Encoder :137-163, for the
+// 1 + 10 + 10 sentences the reference encodes one at a time, siamese_contrastive.py:706-711).
+// Rows = non-pad tokens of all sentences, packed back to back: padding never enters a product
+// (pad keys are masked to exp(-1e9)=0 in the reference and pad positions are dropped from the
+// latent sum by src_mask, model.py:240), so the packed result equals the padded one.
+#include "st_gemm.h"
+
+__global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
+                                                        const int32_t* __restrict__ tok, const int32_t* __restrict__ pos,
+                                                        int R, int vocab, float* __restrict__ x) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const int t = min(max(tok[r], 0), vocab - 1);
+  const f32x4 e = *(const f32x4*)(emb + (size_t)t * 256 + lane * 4);
+  const f32x4 p = *(const f32x4*)(pe + (size_t)pos[r] * 256 + lane * 4);
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;
+}
+
+// full (non-causal) self-attention inside each sentence; block = sentence, wave = head,
+// lane j = key j (sentence length <= 64), then lane d = output dim.  qkv rows: [q | k | v] (768).
+__global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
+                                                       float* __restrict__ out) {
+  const int s = blockIdx.x;
+  const int r0 = off[s], len = off[s + 1] - r0;
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  if (len <= 0) return;
+  // this lane's key row (head slice) stays in registers for all queries
+  f32x4 kreg[16];
+  if (lane < len) {
+    const float* kr = qkv + (size_t)(r0 + lane) * 768 + 256 + h * 64;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) kreg[d] = *(const f32x4*)(kr + d * 4);
+  }
+  for (int i = 0; i < len; ++i) {
+    const float* qr = qkv + (size_t)(r0 + i) * 768 + h * 64;
+    float sc = -INFINITY;
+    if (lane < len) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        const f32x4 qv = *(const f32x4*)(qr + d * 4);
+        acc = fmaf(qv.x, kreg[d].x, acc);
+        acc = fmaf(qv.y, kreg[d].y, acc);
+        acc = fmaf(qv.z, kreg[d].z, acc);
+        acc = fmaf(qv.w, kreg[d].w, acc);
+      }
+      sc = acc * 0.125f;
+    }
+    const float m = wave_max(sc);
+    const float e = lane < len ? expf(sc - m) : 0.0f;
+    const float p = e / wave_sum(e);
+    float o = 0.0f;
+    for (int j = 0; j < len; ++j) o = fmaf(__shfl(p, j, 64), qkv[(size_t)(r0 + j) * 768 + 512 + h * 64 + lane], o);
+    out[(size_t)(r0 + i) * 256 + h * 64 + lane] = o;
+  }
+}
+
+// latent[s] = sum over the sentence's rows of sigmoid(LayerNorm_f(x[row]))   (model.py:236-240)
+__global__ __launch_bounds__(256) void enc_latent_kernel(const float* __restrict__ x, const int32_t* __restrict__ off,
+                                                         int n_sent, const float* __restrict__ ln_a,
+                                                         const float* __restrict__ ln_b, float* __restrict__ latent) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_sent) return;
+  const int lane = threadIdx.x & 63;
+  const f32x4 ga = *(const f32x4*)(ln_a + lane * 4), gb = *(const f32x4*)(ln_b + lane * 4);
+  f32x4 acc = {0, 0, 0, 0};
+  for (int r = off[s]; r < off[s + 1]; ++r) {
+    const f32x4 y = layernorm256(*(const f32x4*)(x + (size_t)r * 256 + lane * 4), ga, gb);
+    acc.x += 1.0f / (1.0f + expf(-y.x));
+    acc.y += 1.0f / (1.0f + expf(-y.y));
+    acc.z += 1.0f / (1.0f + expf(-y.z));
+    acc.w += 1.0f / (1.0f + expf(-y.w));
+  }
+  *(f32x4*)(latent + (size_t)s * 256 + lane * 4) = acc;
+}
+
+static inline size_t enc_align(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" size_t st_encode_workspace_bytes(const StEncoderWeights* w, int n_rows, int n_sent) {
+  if (!w || n_rows <= 0) return 0;
+  (void)n_sent;
+  return enc_align((size_t)n_rows * 256 * 4) * 2 + enc_align((size_t)n_rows * 768 * 4) +
+         enc_align((size_t)n_rows * w->d_ff * 4);
+}
+
+extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens, const int32_t* tok_pos,
+                                const int32_t* sent_off, int n_rows, int n_sent, int max_sent_len, float* latent,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(w != nullptr, "weights struct is NULL");
+  ST_CHECK_ARG(w->d_model == ST_D && w->n_heads == 4, "d_model=%d n_heads=%d unsupported (256, 4)", w->d_model, w->n_heads);
+  ST_CHECK_ARG(w->d_ff > 0 && w->d_ff % 32 == 0, "d_ff=%d must be a positive multiple of 32", w->d_ff);
+  ST_CHECK_ARG(w->n_layers >= 1 && w->n_layers <= ST_MAX_LAYERS, "n_layers=%d", w->n_layers);
+  ST_CHECK_ARG(n_rows >= 0 && n_sent >= 0, "n_rows=%d n_sent=%d", n_rows, n_sent);
+  ST_CHECK_ARG(max_sent_len <= 64 && max_sent_len <= w->pe_rows, "max_sent_len=%d unsupported (<= 64 and <= pe_rows)", max_sent_len);
+  if (n_sent == 0) return ST_OK;
+  ST_CHECK_ARG(sent_off && latent, "NULL buffer");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows == 0) {
+    ST_HIP(hipMemsetAsync(latent, 0, (size_t)n_sent * 256 * 4, st));
+    return ST_OK;
+  }
+  ST_CHECK_ARG(tokens && tok_pos && workspace, "NULL buffer");
+  const size_t need = st_encode_workspace_bytes(w, n_rows, n_sent);
+  if (need > workspace_bytes) {
+    st_set_error("encode workspace too small: need %zu bytes, have %zu", need, workspace_bytes);
+    return ST_ENOMEM;
+  }
+  char* base = (char*)workspace;
+  float* x = (float*)base; base += enc_align((size_t)n_rows * 256 * 4);
+  float* att = (float*)base; base += enc_align((size_t)n_rows * 256 * 4);
+  float* qkv = (float*)base; base += enc_align((size_t)n_rows * 768 * 4);
+  float* h = (float*)base;
+  const int R = n_rows;
+  hipLaunchKernelGGL(enc_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->emb, w->pe, tokens, tok_pos, R, w->vocab, x);
+  ST_LAUNCH_CHECK();
+  for (int l = 0; l < w->n_layers; ++l) {
+    const StEncLayer& y = w->layer[l];
+    ST_CHECK_ARG(y.ln0_a && y.ln0_b && y.wqkv && y.bqkv && y.wo && y.bo && y.ln1_a && y.ln1_b && y.w1 && y.b1 && y.w2 && y.b2,
+                 "NULL weight pointer in encoder layer %d", l);
+    GemmArgs g = {};
+    g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
+    g.out = qkv; g.ldo = 768;
+    ST_TRY(launch_panel<EPI_BIAS>(g, R, 3, st));
+    hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+    ST_LAUNCH_CHECK();
+    GemmArgs o = {};
+    o.X = att; o.n_host = R; o.W = y.wo; o.bias = y.bo; o.N = 256; o.out = x; o.ldo = 256; o.resid = x;
+    ST_TRY(launch_panel<EPI_RESID>(o, R, 1, st));
+    GemmArgs f1 = {};
+    f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
+    f1.out = h; f1.ldo = w->d_ff;
+    ST_TRY(launch_panel<EPI_RELU>(f1, R, (w->d_ff + 255) / 256, st));
+    GemmArgs f2 = {};
+    f2.X = h; f2.n_host = R; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256; f2.out = x; f2.ldo = 256; f2.resid = x;
+    ST_TRY(launch_kloop<EPI_RESID>(f2, R, st));
+  }
+  hipLaunchKernelGGL(enc_latent_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, x, sent_off, n_sent, w->lnf_a, w->lnf_b, latent);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}

@@ -17,13 +17,14 @@
 #define ST_LDA 260  // panel row stride in floats (256 + 4)
 #define ST_LDW 36   // W-stage row stride in floats (32 + 4)
 
-enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_QKV = 3, EPI_ARGMAX = 4 };
+enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_QKV = 3, EPI_ARGMAX = 4, EPI_LSE = 5, EPI_DS = 6 };
 
 struct GemmArgs {
   const float* X;      // [n, K] row-major
   const int* n_dev;    // device row count (may be null -> n_host)
   int n_host;
   int K;               // kloop only (panel: 256)
+  int ldx, ldw;        // kloop with AT / WT only
   const float* ln_a;   // panel only: LayerNorm gain/bias applied to X rows (null = none)
   const float* ln_b;
   const float* W;      // [N, K] row-major (nn.Linear layout)
@@ -43,7 +44,27 @@ struct GemmArgs {
   long kv_stride;
   // ARGMAX: partial[row*gridDim.y + blockIdx.y] = (best, bits(best index), second best, 0)
   float4* partial;
+  // LSE / DS (in-batch InfoNCE, st_simloss.hip): s = acc * scale; target column of row r is row_offset + r.
+  //  LSE: partial[row*gridDim.y + blockIdx.y] = (running max, sum exp(s - max), s[target] or 0, 0)
+  //  DS : out[row*ldo + col] = g[row] * (exp(s - lse[row]) - [col == target]) * scale
+  float scale;
+  int row_offset;
+  const float* lse;
+  const float* g;
 };
+
+struct Lse {
+  float m, l;
+};
+__device__ __forceinline__ Lse lse_merge(Lse a, Lse b) {
+  if (b.m == -INFINITY) return a;
+  if (a.m == -INFINITY) return b;
+  const float m = fmaxf(a.m, b.m);
+  Lse r;
+  r.m = m;
+  r.l = a.l * expf(a.m - m) + b.l * expf(b.m - m);
+  return r;
+}
 
 struct Top2 {
   float m1;
@@ -119,6 +140,19 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(GemmArgs a) {
       }
   }
 
+  Lse run[2][16];
+  float tgt[2][16];
+  if (EPI == EPI_LSE) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        run[mi][r].m = -INFINITY;
+        run[mi][r].l = 0.0f;
+        tgt[mi][r] = 0.0f;
+      }
+  }
+
   const int total = (t_end - t_begin) * 8;
   f32x4 wreg[4];
   // W tile stage: 256 rows x 32 floats = 2048 float4, 4 per thread
@@ -171,7 +205,7 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(GemmArgs a) {
       // ---- epilogue for N tile t ----
       const int col = ((t_begin + (it >> 3)) << 8) + wave * 32 + l31;
       const bool colok = col < a.N;
-      const float bv = colok ? a.bias[col] : 0.0f;
+      const float bv = (colok && a.bias) ? a.bias[col] : 0.0f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const f32x16 acc = mi ? acc1 : acc0;
@@ -186,6 +220,15 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(GemmArgs a) {
             t.m2 = gt ? t.m1 : fmaxf(t.m2, v);
             t.i1 = gt ? col : t.i1;
             t.m1 = gt ? v : t.m1;
+          } else if (EPI == EPI_LSE) {
+            if (colok) {
+              const float sv = v * a.scale;
+              Lse& u = run[mi][r];
+              const float mn = fmaxf(u.m, sv);
+              u.l = u.l * expf(u.m - mn) + expf(sv - mn);
+              u.m = mn;
+              if (col == a.row_offset + row) tgt[mi][r] = sv;
+            }
           } else if (row < n && colok) {
             if (EPI == EPI_BIAS) {
               a.out[(size_t)row * a.ldo + col] = v;
@@ -195,6 +238,10 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(GemmArgs a) {
               v += a.resid[(size_t)row * a.ldo + col];
               if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
               a.out[(size_t)row * a.ldo + col] = v;
+            } else if (EPI == EPI_DS) {
+              const float sv = v * a.scale;
+              const float pr = expf(sv - a.lse[row]) - (col == a.row_offset + row ? 1.0f : 0.0f);
+              a.out[(size_t)row * a.ldo + col] = a.g[row] * pr * a.scale;
             } else if (EPI == EPI_QKV) {
               if (col < 256) {
                 a.q[(size_t)row * 256 + col] = v;
@@ -251,6 +298,42 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(GemmArgs a) {
       a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, 0.0f);
     }
   }
+
+  if (EPI == EPI_LSE) {
+    float* red = Ws;  // [8 waves][64 rows][4]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        Lse t = run[mi][r];
+        float tg = tgt[mi][r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          Lse u;
+          u.m = __shfl_xor(t.m, o, 64);
+          u.l = __shfl_xor(t.l, o, 64);
+          t = lse_merge(t, u);
+          tg += __shfl_xor(tg, o, 64);
+        }
+        if (l31 == 0) {
+          float* p = red + (wave * 64 + mi * 32 + mfma32_row(r, lane)) * 4;
+          p[0] = t.m;
+          p[1] = t.l;
+          p[2] = tg;
+        }
+      }
+    __syncthreads();
+    if (tid < 64 && m0 + tid < n) {
+      Lse t = {red[tid * 4 + 0], red[tid * 4 + 1]};
+      float tg = red[tid * 4 + 2];
+      for (int w = 1; w < 8; ++w) {
+        Lse u = {red[(w * 64 + tid) * 4 + 0], red[(w * 64 + tid) * 4 + 1]};
+        t = lse_merge(t, u);
+        tg += red[(w * 64 + tid) * 4 + 2];
+      }
+      a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m, t.l, tg, 0.0f);
+    }
+  }
 }
 
 #define ST_PANEL_LDS ((64 * ST_LDA + 2 * 256 * ST_LDW) * 4)
@@ -259,7 +342,8 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(GemmArgs a) {
 // kloop_gemm: 128x128 tile, BK = 32, 256 threads (2x2 waves, each 64x64 = 2x2 MFMA tiles).
 // Epilogue: BIAS / RELU / RESID (same meaning as above).
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
+// AT: X is given transposed, [K, n] row-major (ld = a.ldx);  WT: W is given transposed, [K, N] (ld = a.ldw)
+template <int EPI, bool AT = false, bool WT = false>
 __global__ __launch_bounds__(256) void kloop_gemm_kernel(GemmArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;                        // [2][128][ST_LDW]
@@ -281,8 +365,18 @@ __global__ __launch_bounds__(256) void kloop_gemm_kernel(GemmArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int f = tid + i * 256;
       const int r = f >> 3, c4 = f & 7;
-      areg[i] = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * K + k0 + c4 * 4);
-      wreg[i] = *(const f32x4*)(a.W + (size_t)min(n0 + r, a.N - 1) * K + k0 + c4 * 4);
+      if (!AT) {
+        areg[i] = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * K + k0 + c4 * 4);
+      } else {  // 32 k-rows x 32 float4 along m; caller guarantees n % 4 == 0 and ldx % 4 == 0
+        const int kk = f >> 5, m4 = f & 31;
+        areg[i] = *(const f32x4*)(a.X + (size_t)(k0 + kk) * a.ldx + min(m0 + m4 * 4, n - 4));
+      }
+      if (!WT) {
+        wreg[i] = *(const f32x4*)(a.W + (size_t)min(n0 + r, a.N - 1) * K + k0 + c4 * 4);
+      } else {
+        const int kk = f >> 5, m4 = f & 31;
+        wreg[i] = *(const f32x4*)(a.W + (size_t)(k0 + kk) * a.ldw + min(n0 + m4 * 4, a.N - 4));
+      }
     }
   };
   auto sstore = [&](int buf) {
@@ -290,8 +384,19 @@ __global__ __launch_bounds__(256) void kloop_gemm_kernel(GemmArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int f = tid + i * 256;
       const int r = f >> 3, c4 = f & 7;
-      *(f32x4*)(As + buf * 128 * ST_LDW + r * ST_LDW + c4 * 4) = areg[i];
-      *(f32x4*)(Ws + buf * 128 * ST_LDW + r * ST_LDW + c4 * 4) = wreg[i];
+      const int kk = f >> 5, m4 = f & 31;
+      if (!AT) {
+        *(f32x4*)(As + buf * 128 * ST_LDW + r * ST_LDW + c4 * 4) = areg[i];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[buf * 128 * ST_LDW + (m4 * 4 + j) * ST_LDW + kk] = areg[i][j];
+      }
+      if (!WT) {
+        *(f32x4*)(Ws + buf * 128 * ST_LDW + r * ST_LDW + c4 * 4) = wreg[i];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ws[buf * 128 * ST_LDW + (m4 * 4 + j) * ST_LDW + kk] = wreg[i][j];
+      }
     }
   };
   gload(0);
@@ -349,3 +454,40 @@ __global__ __launch_bounds__(256) void kloop_gemm_kernel(GemmArgs a) {
     }
 }
 #define ST_KLOOP_LDS (4 * 128 * ST_LDW * 4)
+
+// ---- host-side launch helpers ----
+template <int EPI>
+static int launch_panel(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)panel_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               ST_PANEL_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  dim3 grid((n_bound + 63) / 64, splits);
+  hipLaunchKernelGGL(panel_gemm_kernel<EPI>, grid, dim3(512), ST_PANEL_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+template <int EPI, bool AT = false, bool WT = false>
+static int launch_kloop(const GemmArgs& a, int n_bound, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)kloop_gemm_kernel<EPI, AT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               ST_KLOOP_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  dim3 grid((n_bound + 127) / 128, (a.N + 127) / 128);
+  hipLaunchKernelGGL((kloop_gemm_kernel<EPI, AT, WT>), grid, dim3(256), ST_KLOOP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+#define ST_TRY(x)            \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != ST_OK) return rc_; \
+  } while (0)
+

@@ -1,0 +1,162 @@
+// In-batch InfoNCE similarity loss, forward and backward (the B x B block of
+// train_ae_model_constraint, /root/reference/method/yelp/siamese_contrastive.py:1060-1069:
+// sim = cosine_similarity(ori[:,None,:], like[None,:,:]) / tau; log_softmax; NLL(target = arange(B))).
+// The reference materialises a [B,B,256] broadcast (68 GB at B = 8192); here
+//   fwd: unit-normalise rows once, then one panel GEMM whose epilogue keeps an online
+//        (max, sum-exp, target) per row — the [Bq,Bk] matrix never exists;
+//   bwd: dS is produced in row chunks of <= 1024 rows (<= 32 MiB at Bk = 8192: Infinity-Cache
+//        resident) by recomputing S from the saved logsumexp, and consumed at once by two GEMMs:
+//        d_ou = dS . ku   and   d_ku += dS^T . ou.
+#include "st_gemm.h"
+
+#define SL_SPLITS 4
+#define SL_CHUNK 1024
+
+// u = x / max(||x||, 1e-8), nrm = max(||x||, 1e-8); wave per row.  ut (optional) = u transposed [256, n]
+__global__ __launch_bounds__(256) void unit_rows_kernel(const float* __restrict__ x, int n, float* __restrict__ u,
+                                                        float* __restrict__ nrm, float* __restrict__ ut) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 v = *(const f32x4*)(x + (size_t)r * 256 + lane * 4);
+  const float nn = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w)), 1e-8f);
+  v = v / nn;
+  *(f32x4*)(u + (size_t)r * 256 + lane * 4) = v;
+  if (lane == 0) nrm[r] = nn;
+  if (ut) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ut[(size_t)(lane * 4 + j) * n + r] = v[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void lse_merge_kernel(const float4* __restrict__ partial, int nsplit, int n,
+                                                        float* __restrict__ loss, float* __restrict__ lse) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  Lse t = {-INFINITY, 0.0f};
+  float tg = 0.0f;
+  for (int k = 0; k < nsplit; ++k) {
+    const float4 p = partial[(size_t)r * nsplit + k];
+    Lse u = {p.x, p.y};
+    t = lse_merge(t, u);
+    tg += p.z;
+  }
+  const float l = t.m + logf(t.l);
+  lse[r] = l;
+  loss[r] = l - tg;
+}
+
+// dx = (du - (du . u) u) / nrm  (backward of x -> x / max(||x||, eps));  out = or += dx
+__global__ __launch_bounds__(256) void unit_rows_bwd_kernel(const float* __restrict__ du, const float* __restrict__ u,
+                                                            const float* __restrict__ nrm, int n,
+                                                            float* __restrict__ dx, int accumulate) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const f32x4 g = *(const f32x4*)(du + (size_t)r * 256 + lane * 4);
+  const f32x4 v = *(const f32x4*)(u + (size_t)r * 256 + lane * 4);
+  const float d = wave_sum(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w);
+  f32x4 o = (g - d * v) / nrm[r];
+  float* p = dx + (size_t)r * 256 + lane * 4;
+  if (accumulate) o += *(const f32x4*)p;
+  *(f32x4*)p = o;
+}
+
+static inline size_t sl_align(size_t v) { return (v + 255) / 256 * 256; }
+
+struct SlWs {
+  float *ou, *ku, *kut, *on, *kn, *dou, *dku, *ds;
+  float4* partial;
+  size_t total;
+};
+static SlWs sl_carve(int Bq, int Bk, char* base) {
+  SlWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += sl_align(bytes);
+    return p;
+  };
+  w.ou = (float*)take((size_t)Bq * 1024);
+  w.ku = (float*)take((size_t)Bk * 1024);
+  w.kut = (float*)take((size_t)Bk * 1024);
+  w.on = (float*)take((size_t)Bq * 4);
+  w.kn = (float*)take((size_t)Bk * 4);
+  w.dou = (float*)take((size_t)Bq * 1024);
+  w.dku = (float*)take((size_t)Bk * 1024);
+  w.partial = (float4*)take((size_t)Bq * SL_SPLITS * 16);
+  w.ds = (float*)take((size_t)(Bq < SL_CHUNK ? Bq : SL_CHUNK) * Bk * 4);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t st_simloss_scratch_bytes(int Bq, int Bk) {
+  if (Bq <= 0 || Bk <= 0) return 0;
+  return sl_carve(Bq, Bk, nullptr).total;
+}
+
+static int sl_check(const float* ori, const float* like, int Bq, int Bk, float tau, int row_offset, void* scratch,
+                    size_t scratch_bytes) {
+  ST_CHECK_ARG(Bq > 0 && Bk > 0, "Bq=%d Bk=%d", Bq, Bk);
+  ST_CHECK_ARG(ori && like && scratch, "NULL buffer");
+  ST_CHECK_ARG(tau > 0.0f, "tau=%g", (double)tau);
+  ST_CHECK_ARG(row_offset >= 0 && row_offset + Bq <= Bk, "targets row_offset+[0,Bq) must lie inside [0,Bk): row_offset=%d", row_offset);
+  const size_t need = st_simloss_scratch_bytes(Bq, Bk);
+  if (need > scratch_bytes) {
+    st_set_error("simloss scratch too small: need %zu bytes, have %zu", need, scratch_bytes);
+    return ST_ENOMEM;
+  }
+  return ST_OK;
+}
+
+extern "C" int st_simloss_fwd(const float* ori, const float* like, int Bq, int Bk, float tau, int row_offset,
+                              float* loss, float* lse, void* scratch, size_t scratch_bytes, void* stream) {
+  ST_TRY(sl_check(ori, like, Bq, Bk, tau, row_offset, scratch, scratch_bytes));
+  ST_CHECK_ARG(loss && lse, "NULL output");
+  hipStream_t st = (hipStream_t)stream;
+  SlWs w = sl_carve(Bq, Bk, (char*)scratch);
+  hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
+  hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, (float*)nullptr);
+  ST_LAUNCH_CHECK();
+  GemmArgs g = {};
+  g.X = w.ou; g.n_host = Bq; g.W = w.ku; g.N = Bk; g.scale = 1.0f / tau; g.row_offset = row_offset; g.partial = w.partial;
+  ST_TRY(launch_panel<EPI_LSE>(g, Bq, SL_SPLITS, st));
+  hipLaunchKernelGGL(lse_merge_kernel, dim3((Bq + 255) / 256), dim3(256), 0, st, w.partial, SL_SPLITS, Bq, loss, lse);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int Bk, float tau, int row_offset,
+                              const float* lse, const float* g, float* d_ori, float* d_like, void* scratch,
+                              size_t scratch_bytes, void* stream) {
+  ST_TRY(sl_check(ori, like, Bq, Bk, tau, row_offset, scratch, scratch_bytes));
+  ST_CHECK_ARG(lse && g && d_ori && d_like, "NULL buffer");
+  ST_CHECK_ARG(Bq % 32 == 0 && Bk % 32 == 0, "backward needs Bq and Bk to be multiples of 32 (Bq=%d Bk=%d)", Bq, Bk);
+  hipStream_t st = (hipStream_t)stream;
+  SlWs w = sl_carve(Bq, Bk, (char*)scratch);
+  hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
+  hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, w.kut);
+  ST_LAUNCH_CHECK();
+  ST_HIP(hipMemsetAsync(w.dku, 0, (size_t)Bk * 1024, st));
+  for (int r0 = 0; r0 < Bq; r0 += SL_CHUNK) {
+    const int rows = (Bq - r0 < SL_CHUNK) ? Bq - r0 : SL_CHUNK;
+    // dS chunk [rows, Bk]
+    GemmArgs a = {};
+    a.X = w.ou + (size_t)r0 * 256; a.n_host = rows; a.W = w.ku; a.N = Bk; a.scale = 1.0f / tau;
+    a.row_offset = row_offset + r0; a.lse = lse + r0; a.g = g + r0; a.out = w.ds; a.ldo = Bk;
+    ST_TRY(launch_panel<EPI_DS>(a, rows, (Bk + 1023) / 1024, st));
+    // d_ou[chunk] = dS . ku   (W = ku^T [256, Bk])
+    GemmArgs b = {};
+    b.X = w.ds; b.n_host = rows; b.K = Bk; b.W = w.kut; b.N = 256; b.out = w.dou + (size_t)r0 * 256; b.ldo = 256;
+    ST_TRY(launch_kloop<EPI_BIAS>(b, rows, st));
+    // d_ku += dS^T . ou[chunk]   (X given transposed: dS [K=rows, n=Bk]; W given transposed: ou chunk [K=rows, 256])
+    GemmArgs c = {};
+    c.X = w.ds; c.ldx = Bk; c.n_host = Bk; c.K = rows; c.W = w.ou + (size_t)r0 * 256; c.ldw = 256; c.N = 256;
+    c.out = w.dku; c.ldo = 256; c.resid = w.dku;
+    ST_TRY((launch_kloop<EPI_RESID, true, true>(c, Bk, st)));
+  }
+  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, w.dou, w.ou, w.on, Bq, d_ori, 0);
+  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, w.dku, w.ku, w.kn, Bk, d_like, 1);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}

@@ -1,0 +1,256 @@
+"""CLI with the flags, defaults, file layout and log format of the reference's method/yelp/main.py
+(/root/reference/method/yelp/main.py:35-126, __main__ :427-493) for the `--attack` path:
+
+    cd method/yelp && python -m style_transfer_amd.main --attack --not_nll --pos_victim_lr=0.2 --neg_victim_lr=0.2
+
+reads  ../../data/<task>/processed_files/{word_to_id.txt,neg10_pos10_test{0,1}.json}
+       save/origin/{constraint_ae_model0_params.pkl,siamese_model_params.pkl,predictor_net_params.pkl}
+writes ./loggings/<victim_optimizer>+<victim_lr>+iter<attack_max_iter>[date time]   (the *_log file
+       outputs/get_i_iter.py parses).
+
+Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N -m style_transfer_amd.main ...`;
+the sentence list is split into N contiguous shards (one process per GPU, no communication while
+computing), the per-sentence records are gathered to rank 0 (RCCL all_gather over xGMI) and rank 0
+writes the log in global sentence order.  Training (`main.py` without --attack) is out of scope.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+MY_VERSION = 1.242  # main.py:25, echoed in the banner
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Here is your model discription.")
+    # main.py:36-39
+    p.add_argument('--id_pad', type=int, default=0)
+    p.add_argument('--id_unk', type=int, default=1)
+    p.add_argument('--id_bos', type=int, default=2)
+    p.add_argument('--id_eos', type=int, default=3)
+    # main.py:44-47
+    p.add_argument('--task', type=str, default='yelp')
+    p.add_argument('--word_to_id_file', type=str, default='')
+    p.add_argument('--data_path', type=str, default='')
+    # main.py:52-60 (VAE parameters: parsed, unused by --attack)
+    p.add_argument('--encoder_emb_dim', type=int, default=256)
+    p.add_argument('--decoder_emb_dim', type=int, default=256)
+    p.add_argument('--encoder_hidden_dim', type=int, default=256)
+    p.add_argument('--decoder_hidden_dim', type=int, default=256)
+    p.add_argument('--encoder_dropout', type=float, default=0.5)
+    p.add_argument('--decoder_dropout', type=float, default=0.5)
+    p.add_argument('--AE_LATENT_NUM', type=int, default=80)
+    p.add_argument('--max_epoch', type=int, default=80)
+    # main.py:66-77
+    p.add_argument('--word_dict_max_num', type=int, default=5)
+    p.add_argument('--batch_size', type=int, default=128)
+    p.add_argument('--max_sequence_length', type=int, default=60)
+    p.add_argument('--num_layers_AE', type=int, default=2)
+    p.add_argument('--transformer_model_size', type=int, default=256)
+    p.add_argument('--transformer_ff_size', type=int, default=1024)
+    p.add_argument('--latent_size', type=int, default=256)
+    p.add_argument('--word_dropout', type=float, default=1.0)
+    p.add_argument('--embedding_dropout', type=float, default=0.5)
+    p.add_argument('--learning_rate', type=float, default=0.001)
+    p.add_argument('--label_size', type=int, default=1)
+    # main.py:82-94
+    p.add_argument('--train_siamese_lr', type=float, default=3e-3)
+    p.add_argument('--simplest_siamese', action='store_true')
+    p.add_argument('--negative_samples', action='store_true')
+    p.add_argument('--tfidf_train', action='store_true')
+    p.add_argument('--anneal_epoch', type=int, default=100)
+    p.add_argument('--use_min', action='store_true')
+    p.add_argument('--tau', type=float, default=0.1)
+    p.add_argument('--bata', type=float, default=0.1)
+    p.add_argument('--together', action='store_true')
+    # main.py:100-124
+    p.add_argument('--victim_optimizer', type=str, default='Adam')
+    p.add_argument('--victim_lr', type=float, default=0.25)
+    p.add_argument('--attack_max_iter', type=int, default=18)
+    p.add_argument('--attack_max_change', type=int, default=7)
+    p.add_argument('--reverse_order', action='store_true')
+    p.add_argument('--diff', action='store_true')
+    p.add_argument('--just_use_one', action='store_true')
+    p.add_argument('--attack', action='store_true')
+    p.add_argument('--retext', action='store_true')
+    p.add_argument('--not_nll', action='store_true')
+    p.add_argument('--early_stop', action='store_true')
+    p.add_argument('--dance', action='store_true')
+    p.add_argument('--pos_num', type=int, default=None)
+    p.add_argument('--neg_num', type=int, default=None)
+    p.add_argument('--pos_victim_lr', type=float, default=0.25)
+    p.add_argument('--neg_victim_lr', type=float, default=0.25)
+    # build-side options (no reference counterpart; defaults reproduce the reference's behaviour)
+    g = p.add_argument_group("MI355X build options")
+    g.add_argument('--attack_batch', type=int, default=256, help='sentences processed together per GPU')
+    g.add_argument('--save_path', type=str, default=None, help="checkpoint directory (default save/origin/)")
+    g.add_argument('--ae_checkpoint', type=str, default='constraint_ae_model0_params.pkl')
+    g.add_argument('--limit', type=int, default=None, help='only the first N sentences of each test file')
+    g.add_argument('--log_file', type=str, default=None, help='log path (default ./loggings/<reference name>)')
+    g.add_argument('--no_log_decodes', action='store_true', help='skip the Rec/Sim/Ref decodes (lines omitted)')
+    g.add_argument('--fixed_decode_steps', action='store_true', help='always run max_sequence_length-1 decode steps')
+    g.add_argument('--quiet', action='store_true', help='do not echo log records on stdout')
+    return p
+
+
+def dist_info():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def shard_range(n, rank, world):
+    """contiguous split of range(n) over ranks, sizes differing by at most one"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_results(res, world, backend_device):
+    """rank-ordered concatenation of the per-shard records on every rank (RCCL all_gather on device
+    tensors when backend_device is a GPU; gloo/CPU in the tests)."""
+    import torch
+    import torch.distributed as dist
+    from .attack import AttackResult
+    fields = ["n_iter", "init_ids", "iter_ids", "changed", "like_ids", "unlike_ids"]
+    out = {}
+    for f in fields:
+        a = getattr(res, f)
+        if a is None:
+            out[f] = None
+            continue
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(backend_device)
+        n = torch.tensor([t.shape[0]], device=backend_device)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        mx = int(max(x.item() for x in ns))
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=backend_device)
+        pad[: t.shape[0]] = t
+        parts = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        out[f] = np.concatenate([p[: int(k.item())].cpu().numpy() for p, k in zip(parts, ns)], 0)
+    return AttackResult(**out)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    args.if_load_from_checkpoint = True        # main.py:130-131
+    args.checkpoint_name = "origin"
+    if not args.attack:
+        sys.exit("only the --attack path is implemented (training is out of scope, SURVEY.md §8)")
+    import torch
+    from . import weights as W
+    from .attack import AttackConfig, AttackRunner, concat_results, write_attack_log
+    from .data import AttackSet, load_word_dict_info
+    from .logfmt import LogWriter, headline
+
+    rank, world, local = dist_info()
+    if not torch.cuda.is_available():
+        sys.exit("no GPU visible: the attack path runs on HIP kernels only (no CPU fallback)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    # initialize_logging (siamese_contrastive.py:1595-1605): the name uses --victim_lr, not pos/neg lr
+    log = None
+    if rank == 0:
+        now_time = time.strftime("[%Y-%m-%d %H%M%S]", time.localtime())
+        path = args.log_file
+        if path is None:
+            os.makedirs('./loggings', exist_ok=True)
+            path = os.path.join('./loggings', args.victim_optimizer + '+' + str(args.victim_lr) + '+iter' + str(args.attack_max_iter) + now_time)
+        print('Saving Siamese Log to {}'.format(path))
+        os.makedirs('./outputs', exist_ok=True)  # initialize_output, :1608-1611
+        print('--- Running Siamese Style Transfer, Version{}'.format(MY_VERSION))
+        print('--- Cuda: {}'.format(True))
+        log = LogWriter(path, echo=not args.quiet)
+        # print_basic_information (main.py:413-425)
+        log('Path: {}'.format(os.path.abspath('.')))
+        log('--- Checkpoint Path: {}'.format(args.checkpoint_name))
+        log('--- AE Model Name: {}'.format(args.ae_checkpoint))
+        log('--- Attack: {}'.format(args.attack))
+        log('--- pos_num: {}'.format(args.pos_num))
+        log('--- neg_num: {}'.format(args.neg_num))
+        log('--- pos_victim_lr: {}'.format(args.pos_victim_lr))
+        log('--- neg_victim_lr: {}'.format(args.neg_victim_lr))
+        log('--- not_nll: {}'.format(args.not_nll))
+        log('--- simplest_siamese: {}'.format(args.simplest_siamese))
+        log(str(args))
+
+    # preparation (main.py:153-199)
+    save_path = args.save_path or 'save/%s/' % args.checkpoint_name
+    if args.task not in ('yelp', 'amazon'):
+        raise TypeError('Wrong task type!')
+    data_path = args.data_path or '../../data/%s/processed_files/' % args.task
+    if rank == 0:
+        print("prepare data ...")
+    id_to_word, vocab_size = load_word_dict_info(os.path.join(data_path, 'word_to_id.txt'), args.word_dict_max_num)
+
+    ae_sd = W.load_state_dict_file(os.path.join(save_path, args.ae_checkpoint))
+    ae = W.AEWeights(ae_sd, device, max_len=args.max_sequence_length)
+    if ae.vocab != vocab_size:
+        raise ValueError("checkpoint vocabulary %d != word_to_id vocabulary %d" % (ae.vocab, vocab_size))
+    # load_siamese (siamese_contrastive.py:1565-1587): exit(0) when a file is missing
+    sp, pp = os.path.join(save_path, 'siamese_model_params.pkl'), os.path.join(save_path, 'predictor_net_params.pkl')
+    if rank == 0:
+        print('Loading Siamese Net from {}'.format(save_path))
+    if not os.path.exists(sp):
+        print('Siamese Net Path not Exist')
+        sys.exit(0)
+    if not os.path.exists(pp):
+        print('Predictor Net Path Not Exist')
+        sys.exit(0)
+    scorer = W.ScorerWeights(W.load_state_dict_file(sp), W.load_state_dict_file(pp), device)
+
+    files = [os.path.join(data_path, 'neg10_pos10_test0.json'), os.path.join(data_path, 'neg10_pos10_test1.json')]
+    if args.reverse_order:
+        files = files[::-1]
+    if rank == 0:
+        log('Loading attack Dataset, Shuffle=False')
+        log('ori_file_list = {}'.format(files))
+        print('Random Seed is set to 234')
+    data = AttackSet.from_json(files, vocab_size, args.id_unk, args.max_sequence_length, args.pos_num, args.neg_num)
+    if args.limit is not None:
+        half = len(data) // 2
+        keep = list(range(min(args.limit, half))) + list(range(half, half + min(args.limit, half)))
+        data = data.subset(keep)
+    if rank == 0:
+        log(headline('Start Attack via Contrastive Net'))
+        log(headline('Optimizer {}, lr {}, Iter {}'.format(args.victim_optimizer, args.victim_lr, args.attack_max_iter)))
+        log(headline('Attack with Simplest Siamest Net' if args.simplest_siamese else 'Attack with enhance Siamese Net(with Predictor)', note_token='+'))
+
+    cfg = AttackConfig.from_namespace(args, log_decodes=not args.no_log_decodes, early_exit=not args.fixed_decode_steps)
+    runner = AttackRunner(ae, scorer, cfg, device)
+    runner.set_vocab(id_to_word)
+    lo, hi = shard_range(len(data), rank, world)
+    parts = []
+    t0 = time.perf_counter()
+    for b0 in range(lo, hi, args.attack_batch):
+        idx = list(range(b0, min(hi, b0 + args.attack_batch)))
+        parts.append(runner.run_batch(data.subset(idx), idx))
+    res = concat_results(parts) if parts else None
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        res = gather_results(res, world, device)
+        dist.barrier()
+    if rank == 0:
+        write_attack_log(log, data, res, id_to_word, 0, dance=args.dance)
+        log.close()
+        print('Done')
+        print('[st] %d sentences on %d GPU(s): %.2f s compute on rank 0 (%.1f sentences/s)' %
+              (len(data), world, dt, (hi - lo) / max(dt, 1e-9) * world), file=sys.stderr)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,280 @@
+"""GPU parity tests, kernel by kernel, through the C-ABI (style_transfer_amd.ops -> libst_kernels.so),
+against the CPU oracle (oracle/st_oracle.py) on the same seeded inputs.
+
+Tolerances (floating point; the reference computes in f32):
+  * matrix products / activations: 2e-4 relative to the row's max magnitude (f32 accumulation order)
+  * argmax ids: exact wherever the oracle's top-2 logit gap exceeds 1e-3 (near-ties are reported)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, gold
+
+pytestmark = pytest.mark.gpu
+
+import st_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def ae(ae_sd_torch, dev):
+    from style_transfer_amd.weights import AEWeights
+    return AEWeights(ae_sd_torch, dev)
+
+
+@pytest.fixture(scope="module")
+def scorer(scorer_sd_torch, dev):
+    from style_transfer_amd.weights import ScorerWeights
+    return ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev)
+
+
+def some_sentences(n, seed=0):
+    d = json.load(open(os.path.join(GOLD, "yelp", "neg10_pos10_test0.json")))["data"]
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in rng.choice(len(d), n, replace=False):
+        key = ["origin", "ref3", "sim7"][int(i) % 3]
+        out.append([int(x) for x in d[int(i)][key].split()])
+    return out
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+@pytest.mark.parametrize("n,V,ln", [(1, 9339, True), (63, 9339, False), (65, 19724, True), (300, 100, True), (128, 256, False)])
+def test_gemm_argmax(dev, n, V, ln):
+    from style_transfer_amd import ops
+    rng = np.random.default_rng(n + V)
+    h = rng.standard_normal((n, 256)).astype(np.float32) * 3
+    W = (rng.standard_normal((V, 256)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(V).astype(np.float32)
+    a_, b_ = (rng.standard_normal(256).astype(np.float32), rng.standard_normal(256).astype(np.float32))
+    x = O.layer_norm(h, a_, b_) if ln else h
+    logits = x.astype(np.float64) @ W.T.astype(np.float64) + b
+    t = lambda v: torch.from_numpy(v).to(dev)
+    ids, best, gap = ops.gemm_argmax(t(h), t(W), t(b), t(a_) if ln else None, t(b_) if ln else None)
+    ids, best, gap = ids.cpu().numpy(), best.cpu().numpy(), gap.cpu().numpy()
+    srt = np.sort(logits, -1)
+    ref_gap = srt[:, -1] - (srt[:, -2] if V > 1 else 0)
+    clear = ref_gap > 1e-3
+    assert (ids[clear] == logits.argmax(-1)[clear]).all()
+    assert np.abs(best - srt[:, -1]).max() < 2e-4 * max(1.0, np.abs(srt[:, -1]).max())
+    assert np.abs(gap - ref_gap).max() < 1e-3
+
+
+def test_gemm_argmax_ties_pick_lowest_index(dev):
+    """torch.max on CPU returns the first maximal index (model.py:292); exact ties must do the same."""
+    from style_transfer_amd import ops
+    V = 1000
+    h = torch.zeros(70, 256, device=dev)
+    h[:, 0] = 1.0
+    W = torch.zeros(V, 256, device=dev)
+    b = torch.zeros(V, device=dev)
+    for c in (3, 257, 600, 999):
+        W[c, 0] = 2.0
+    ids, best, gap = ops.gemm_argmax(h, W, b)
+    assert (ids.cpu().numpy() == 3).all() and (gap.cpu().numpy() == 0).all()
+
+
+def test_scorer_embed(dev, scorer, scorer_sd):
+    from style_transfer_amd import ops
+    rng = np.random.default_rng(1)
+    x = (rng.random((77, 256)) * 8).astype(np.float32)
+    z = O.siamese_forward(scorer_sd[0], x)
+    got = ops.scorer_embed(scorer, torch.from_numpy(x).to(dev), unit=False).cpu().numpy()
+    assert relerr(got, z) < 2e-5
+    zu = z / np.maximum(np.linalg.norm(z, axis=1, keepdims=True), 1e-8)
+    got = ops.scorer_embed(scorer, torch.from_numpy(x).to(dev), unit=True).cpu().numpy()
+    assert relerr(got, zu) < 2e-5
+
+
+@pytest.mark.parametrize("mode", [dict(not_nll=True), dict(), dict(just_use_one=True), dict(not_nll=True, simplest=True),
+                                  dict(not_nll=True, kp=3, kn=5), dict(kp=1, kn=10)])
+def test_scorer_edit_step(dev, scorer, scorer_sd, mode):
+    """three consecutive iterations of loss / gradient / Adam vs the oracle, per sentence"""
+    from style_transfer_amd import ops
+    mode = dict(mode)
+    kp, kn = mode.pop("kp", 10), mode.pop("kn", 10)
+    ssd, psd = scorer_sd
+    B = 37
+    rng = np.random.default_rng(5)
+    lat = (rng.random((B, 256)) * 8).astype(np.float32)
+    like = (rng.random((B, kp, 256)) * 8).astype(np.float32)
+    unlike = (rng.random((B, kn, 256)) * 8).astype(np.float32)
+    lr = np.where(np.arange(B) % 2 == 0, 0.2, 0.3).astype(np.float32)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    like_z = ops.scorer_embed(scorer, t(like.reshape(-1, 256))).view(B, kp, 256)
+    unlike_z = ops.scorer_embed(scorer, t(unlike.reshape(-1, 256))).view(B, kn, 256)
+    x, m, v = t(lat.copy()), torch.zeros(B, 256, device=dev), torch.zeros(B, 256, device=dev)
+    step = torch.zeros(B, dtype=torch.int32, device=dev)
+    active = torch.ones(B, dtype=torch.uint8, device=dev)
+    active[5] = 0
+    opts = [O.Adam((1, 256), float(lr[b])) for b in range(B)]
+    xo = [lat[b:b + 1].copy() for b in range(B)]
+    sign_mismatch = 0
+    for it in range(3):
+        loss, grad = ops.scorer_edit_step(scorer, x, m, v, like_z, unlike_z, t(lr), step, active, tau=0.1,
+                                          want_loss=True, want_grad=True, **mode)
+        loss, grad, xg = loss.cpu().numpy(), grad.cpu().numpy(), x.cpu().numpy()
+        for b in range(B):
+            if b == 5:
+                assert np.array_equal(xg[b], lat[b])
+                continue
+            lo, go = O.contrastive_loss_and_grad(ssd, psd, xo[b], like[b], unlike[b], 0.1, not_nll=mode.get("not_nll", False),
+                                                 simplest=mode.get("simplest", False), just_use_one=mode.get("just_use_one", False))
+            assert abs(loss[b] - lo) < 1e-4 * max(1, abs(lo)), (it, b, loss[b], lo)
+            assert relerr(grad[b], go[0]) < 1e-3, (it, b, relerr(grad[b], go[0]))
+            sign_mismatch += int((np.sign(grad[b]) != np.sign(go[0])).sum())
+            xo[b] = opts[b].step(xo[b], go)
+            # first Adam step is lr*sign(g): a sign flip of a near-zero gradient moves that coordinate by 2*lr
+            bad = np.abs(xg[b] - xo[b][0]) > 1e-3 * np.abs(xo[b][0]).max()
+            assert bad.sum() <= 1, (it, b, int(bad.sum()))
+            xo[b] = xg[b:b + 1].copy()  # re-sync so a tolerated flip does not compound
+    assert sign_mismatch <= 2
+    assert step.cpu().numpy()[0] == 3 and step.cpu().numpy()[5] == 0
+
+
+def test_encode_latent(dev, ae, ae_sd):
+    from style_transfer_amd import ops
+    from style_transfer_amd.data import pack_sentences
+    sents = some_sentences(40) + [[], [5]]
+    tok, pos, off, mx = pack_sentences(sents)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    got = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx).cpu().numpy()
+    for i, s in enumerate(sents):
+        if not s:
+            assert np.abs(got[i]).max() == 0
+            continue
+        # padded to a longer length on purpose: padding must not change the latent
+        src = np.zeros((1, len(s) + 3), np.int64)
+        src[0, :len(s)] = s
+        ref = O.encode_latent(ae_sd, src)[0]
+        assert relerr(got[i], ref) < 2e-4, (i, relerr(got[i], ref))
+
+
+@pytest.mark.parametrize("early", [True, False])
+def test_greedy_decode(dev, ae, ae_sd, early):
+    from style_transfer_amd import ops
+    sents = some_sentences(24, seed=3)
+    L = max(len(s) for s in sents)
+    src = np.zeros((len(sents), L), np.int64)
+    for i, s in enumerate(sents):
+        src[i, :len(s)] = s
+    lat = O.encode_latent(ae_sd, src)
+    lat[3] += 0.7  # an edited latent
+    ref, ref_gap = O.greedy_decode(ae_sd, lat, 60, early_exit=early, want_gap=True)
+    ids, gap, steps = ops.greedy_decode(ae, torch.from_numpy(lat).to(dev), early_exit=early, want_gap=True)
+    ids, gap = ids.cpu().numpy(), gap.cpu().numpy()
+    assert steps == 59 if not early else steps <= 59
+    n_bad = 0
+    for b in range(len(sents)):
+        end = 59
+        for i in range(59):
+            if ref[b, i] in (0, 3):
+                end = i + 1
+                break
+        upto = end if early else 59
+        if not np.array_equal(ids[b, :upto], ref[b, :upto]):
+            first = int(np.nonzero(ids[b, :upto] != ref[b, :upto])[0][0])
+            assert ref_gap[b, first] < 1e-3, "sentence %d diverges at %d with a clear gap %g" % (b, first, ref_gap[b, first])
+            n_bad += 1
+        else:
+            assert np.abs(gap[b, :upto] - ref_gap[b, :upto]).max() < 2e-3
+        if early:
+            assert (ids[b, end:] == 0).all()
+    assert n_bad <= 1
+
+
+def test_decode_matches_input_sentence(dev, ae, ae_sd):
+    """size-independent property: the surrogate autoencoder reconstructs most of its inputs"""
+    from style_transfer_amd import ops
+    from style_transfer_amd.data import pack_sentences
+    sents = some_sentences(64, seed=9)
+    tok, pos, off, mx = pack_sentences(sents)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    lat = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx)
+    ids, _, _ = ops.greedy_decode(ae, lat)
+    ids = ids.cpu().numpy()
+    ok = sum(1 for i, s in enumerate(sents) if list(ids[i, :len(s)]) == s and ids[i, len(s)] == 3)
+    assert ok >= 40, ok
+
+
+def test_accept_changes(dev):
+    from style_transfer_amd import ops
+    T, B = 59, 6
+    acc = np.zeros((B, T), np.int32)
+    new = np.zeros((B, T), np.int32)
+    acc[:, :4] = [10, 11, 12, 3]
+    new[0, :4] = [10, 11, 12, 3]                    # same
+    new[1, :5] = [10, 11, 12, 13, 3]                # longer
+    new[2, :4] = [10, 11, 3, 99]                    # shorter (junk after EOS ignored)
+    new[3, :4] = [10, 11, 12, 0]; new[3, 5] = 77    # PAD ends like EOS -> same text
+    new[4, :4] = [10, 50000, 12, 3]                 # id >= vocab -> UNK, differs from 11
+    new[5, :4] = [10, 11, 13, 3]                    # inactive row: must be ignored
+    t = lambda v: torch.from_numpy(v).to(dev)
+    acc_d, new_d = t(acc.copy()), t(new)
+    n_changes = torch.tensor([0, 6, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+    changed = torch.zeros(B, dtype=torch.uint8, device=dev)
+    active = torch.tensor([1, 1, 1, 1, 1, 0], dtype=torch.uint8, device=dev)
+    rec = torch.zeros(B, T, dtype=torch.int32, device=dev)
+    ops.accept_changes(new_d, acc_d, 9339, n_changes, changed, active, max_change=7, rec_ids=rec)
+    assert changed.cpu().tolist() == [0, 1, 1, 0, 1, 0]
+    assert n_changes.cpu().tolist() == [0, 7, 1, 0, 1, 0]
+    assert active.cpu().tolist() == [1, 0, 1, 1, 1, 0]
+    a = acc_d.cpu().numpy()
+    assert np.array_equal(a[1], new[1]) and np.array_equal(a[0], acc[0]) and np.array_equal(a[5], acc[5])
+    assert np.array_equal(rec.cpu().numpy()[:5], a[:5])
+
+
+def test_simloss_golden_b128(dev):
+    """reference torch code of siamese_contrastive.py:1060-1069 at B = 128 (fixture simloss_b128.npz)"""
+    from style_transfer_amd import ops
+    g = gold("simloss_b128.npz")
+    ori = torch.from_numpy(g["ori"]).to(dev)
+    d_ori = np.zeros_like(g["ori"])
+    tot = 0.0
+    for v in range(3):
+        like = torch.from_numpy(np.ascontiguousarray(g["like"][v])).to(dev)
+        loss, lse = ops.simloss_fwd(ori, like, tau=float(g["tau"]))
+        assert np.abs(loss.cpu().numpy() - g["loss_rows"][v]).max() < 2e-4
+        tot += float(loss.mean().item()) / 3
+        gr = torch.full((128,), 1.0 / (3 * 128), device=dev)
+        do, dl = ops.simloss_bwd(ori, like, lse, gr, tau=float(g["tau"]))
+        d_ori += do.cpu().numpy()
+        assert relerr(dl.cpu().numpy(), g["d_like"][v]) < 1e-3
+    assert abs(tot - float(g["loss"])) < 1e-4
+    assert relerr(d_ori, g["d_ori"]) < 1e-3
+
+
+@pytest.mark.parametrize("Bq,Bk,off", [(64, 320, 32), (1088, 1088, 0), (96, 2048, 1900)])
+def test_simloss_vs_oracle(dev, Bq, Bk, off):
+    from style_transfer_amd import ops
+    rng = np.random.default_rng(Bq)
+    ori = (rng.random((Bq, 256)) * 10).astype(np.float32)
+    like = (rng.random((Bk, 256)) * 10).astype(np.float32)
+    like[off:off + Bq] += 0.5 * ori
+    gw = rng.random(Bq).astype(np.float32)
+    loss_ref, lse_ref = O.simloss(ori, like, 0.1, off)
+    do_ref, dl_ref = O.simloss_grads(ori, like, gw.astype(np.float64), 0.1, off)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    loss, lse = ops.simloss_fwd(t(ori), t(like), 0.1, off)
+    assert np.abs(loss.cpu().numpy() - loss_ref).max() < 3e-4
+    do, dl = ops.simloss_bwd(t(ori), t(like), lse, t(gw), 0.1, off)
+    assert relerr(do.cpu().numpy(), do_ref) < 1e-3
+    assert relerr(dl.cpu().numpy(), dl_ref) < 1e-3
+
+
+def test_errors_are_reported_not_thrown_across_abi(dev, ae):
+    from style_transfer_amd import ops, _lib
+    with pytest.raises(_lib.StError, match="max_len"):
+        ops.greedy_decode(ae, torch.zeros(2, 256, device=dev), max_len=100)
