@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py — style-transferred sentences/sec on yelp-shaped synthetic batches, N GPUs of one node.
+
+A "step" is one pass of the hot path (encode 1+10+10 sentences, like/unlike scorer embeddings, initial
+decode, then up to 18 edit iterations of scorer fwd/bwd/Adam + greedy decode + change detection) over
+one batch of synthetic yelp-shaped sentences per GPU, with the packed token arrays already resident
+in HBM.  Sentences are independent, so ranks share nothing (weak scaling: fixed batch per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (a numpy port of the reference algorithm, KV-cached decode) on a bounded sample of
+    the same workload, on this box's host cores.  Reported beside the GPU number; not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import st_oracle as O
+    from style_transfer_amd import weights as W
+    from style_transfer_amd.data import AttackSet
+    ae = {k: v.numpy() for k, v in W.expand_ae_state_dict(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors"))).items()}
+    ssd = {k: v.numpy() for k, v in W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")).items()}
+    psd = {k: v.numpy() for k, v in W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")).items()}
+    data = AttackSet.synthetic(64, 9339, "yelp", seed=1234)
+    id_to_word = [str(i) for i in range(9339)]
+    t0 = time.perf_counter()
+    done = 0
+    for s in range(len(data)):
+        enc = lambda sents: O.encode_latent(ae, O.pad_sequences(sents, 9339))
+        ori = enc([data.origin[s]])
+        like, unlike = enc(data.like[s]), enc(data.unlike[s])
+        O.attack_one(ae, ssd, psd, ori, like, unlike, 0.2, id_to_word, lambda m: None, not_nll=True)
+        done += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    return {"value": done / dt, "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic yelp-shaped sentences through oracle/st_oracle.py (numpy f32, batch 1, KV-cached decode with "
+                      "early exit, no log decodes), %.1f s; the imported reference itself ran 12.4 s/sentence on 8 cores (BASELINE.md)" % (done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8192, help="sentences per GPU per step")
+    ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
+    ap.add_argument("--fixed-steps", action="store_true", help="no early exit at EOS: always 59 decode steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from style_transfer_amd import _lib, weights as W
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors")), dev)
+    scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
+                             W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
+    cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, early_exit=not a.fixed_steps)
+    runner = AttackRunner(ae, scorer, cfg, dev)
+    B = a.batch
+    data = AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank)
+    prep = runner.prepare(data)                       # tokens resident in HBM before the timed region
+    gidx = torch.arange(B, device=dev) % 1000
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    L = _lib.lib()
+    for _ in range(a.warmup):
+        runner.run_prepared(prep, gidx, fetch=False)
+    sync()
+    L.st_profile_enable(1)
+    units = 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = runner.run_prepared(prep, gidx, fetch=False)
+        units += r.timing["units"]
+    sync()
+    dt = time.perf_counter() - t0
+    L.st_profile_enable(0)
+    gen_ms, gen_fl, gen_n = C.c_double(), C.c_double(), C.c_longlong()
+    L.st_profile_read(C.byref(gen_ms), C.byref(gen_fl), C.byref(gen_n), 1)
+    n_iter_mean = float(r.device["was_active"].sum().item()) / B
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    if rank == 0:
+        achieved = gen_fl.value / (gen_ms.value * 1e-3) / 1e12 if gen_ms.value > 0 else 0.0
+        out = {
+            "metric": "style-transferred sentences/sec, yelp-shape" if a.shape == "yelp" else "style-transferred sentences/sec, amazon-shape",
+            "value": world * B * a.steps / dt, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d), %d per GPU per step, flags --attack --not_nll "
+                                   "--pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
+                                   "surrogate AE checkpoint + shipped Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes off"
+                                   % (a.shape, B, "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS"),
+                       "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
+                       "mean_edit_iterations_per_sentence": n_iter_mean,
+                       "edit_iteration_units_per_s": world * units / dt},
+            "roofline": {"bound": "mfma", "kernel": "panel_gemm_kernel<EPI_ARGMAX> (generator GEMM + argmax)",
+                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": int(gen_n.value), "avg_launch_us": gen_ms.value * 1e3 / max(1, gen_n.value),
+                         "kernel_time_share": gen_ms.value * 1e-3 / dt},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

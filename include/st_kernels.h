@@ -37,6 +37,14 @@ extern "C" {
 int st_abi_version(void);
 const char* st_last_error(void);
 
+/* Timing of the dominant kernel (generator GEMM + argmax) with HIP events on the caller's stream,
+ * for bench.py's roofline line (no reference counterpart).  While enabled, st_decode_greedy brackets
+ * every generator launch with an event pair; st_profile_read waits for them and returns the summed
+ * kernel milliseconds, the summed algorithmic flops (2 * live_rows * 256 * V per launch; exact when
+ * sync_every == 1) and the launch count; reset != 0 clears the record.                           */
+int st_profile_enable(int on);
+int st_profile_read(double* gen_ms, double* gen_flops, long long* gen_launches, int reset);
+
 /* ---------------------------------------------------------------------------------------------
  * (1) Style scorer: SiameseNet + Predictor + contrastive score + backward-to-latent + Adam.
  * ------------------------------------------------------------------------------------------- */

@@ -50,6 +50,8 @@ EXPORTS = {
     # name: (restype, argtypes)
     "st_abi_version": (C.c_int, []),
     "st_last_error": (C.c_char_p, []),
+    "st_profile_enable": (C.c_int, [C.c_int]),
+    "st_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
     "st_scorer_edit_step": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                       C.c_int, C.c_float, C.c_int, fp, fp, fp]),

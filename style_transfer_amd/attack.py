@@ -70,6 +70,7 @@ class AttackResult:
     final_latent: np.ndarray = None
     trace: dict = field(default_factory=dict)
     timing: dict = field(default_factory=dict)
+    device: dict = None           # run_prepared(fetch=False): the same records as device tensors
 
 
 class AttackRunner:
@@ -88,13 +89,26 @@ class AttackRunner:
         self.canon = None if c is None else torch.from_numpy(c).to(self.device)
 
     # -- pieces -----------------------------------------------------------------------------------
+    ENC_CHUNK = 32768  # sentences per encoder launch sequence (bounds the [rows, d_ff] workspace)
+
+    def prepare(self, batch: AttackSet):
+        """Host -> device: pack the 1 + K+ + K- sentences of every origin (order: all origins, all
+        like groups, all unlike groups) into device token arrays, in chunks of ENC_CHUNK sentences."""
+        sents = list(batch.origin) + [s for grp in batch.like for s in grp] + [s for grp in batch.unlike for s in grp]
+        dev, chunks = self.device, []
+        for c0 in range(0, len(sents), self.ENC_CHUNK):
+            part = sents[c0:c0 + self.ENC_CHUNK]
+            tokens, tok_pos, sent_off, max_len = pack_sentences(part)
+            chunks.append((torch.from_numpy(tokens).to(dev), torch.from_numpy(tok_pos).to(dev),
+                           torch.from_numpy(sent_off).to(dev), len(part), max_len))
+        return dict(chunks=chunks, B=len(batch), kp=batch.n_pos, kn=batch.n_neg)
+
+    def encode_prepared(self, prep):
+        outs = [ops.encode_latent(self.ae, t, p, o, n, mx, ws=self.ws) for (t, p, o, n, mx) in prep["chunks"]]
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
     def encode(self, sents):
-        tokens, tok_pos, sent_off, max_len = pack_sentences(sents)
-        dev = self.device
-        t = torch.from_numpy(tokens).to(dev)
-        p = torch.from_numpy(tok_pos).to(dev)
-        o = torch.from_numpy(sent_off).to(dev)
-        return ops.encode_latent(self.ae, t, p, o, len(sents), max_len, ws=self.ws)
+        return self.encode_prepared(self.prepare(AttackSet(sents, [], [])))
 
     def decode(self, latent, want_gap=False):
         c = self.cfg
@@ -103,15 +117,18 @@ class AttackRunner:
 
     # -- one batch --------------------------------------------------------------------------------
     def run_batch(self, batch: AttackSet, global_index) -> AttackResult:
-        """global_index [B]: position of each sentence in the full run (lr switch at 500, :740)."""
+        return self.run_prepared(self.prepare(batch), global_index)
+
+    def run_prepared(self, prep, global_index, fetch=True) -> AttackResult:
+        """global_index [B]: position of each sentence in the full run (lr switch at 500, :740).
+        fetch=False leaves the records on the device (bench: no D2H inside the timed region)."""
         c, dev = self.cfg, self.device
-        B, kp, kn = len(batch), batch.n_pos, batch.n_neg
+        B, kp, kn = prep["B"], prep["kp"], prep["kn"]
         T = c.max_sequence_length - 1
         I = 2 if c.dance else c.attack_max_iter
         tm = {}
         t0 = time.perf_counter()
-        sents = list(batch.origin) + [s for grp in batch.like for s in grp] + [s for grp in batch.unlike for s in grp]
-        lat_all = self.encode(sents)
+        lat_all = self.encode_prepared(prep)
         ori = lat_all[:B].clone()
         like_lat = lat_all[B:B + B * kp]
         unlike_lat = lat_all[B + B * kp:]
@@ -126,7 +143,7 @@ class AttackRunner:
             init_gap = None
         else:
             init_ids, init_gap, _ = self.decode(ori, want_gap=c.want_gap)
-        gidx = torch.as_tensor(np.asarray(global_index), device=dev)
+        gidx = global_index if torch.is_tensor(global_index) else torch.as_tensor(np.asarray(global_index), device=dev)
         lr = torch.where(gidx < 500, torch.tensor(c.pos_victim_lr, device=dev), torch.tensor(c.neg_victim_lr, device=dev)).float().contiguous()
         m = torch.zeros(B, 256, device=dev)
         v = torch.zeros(B, 256, device=dev)
@@ -171,6 +188,10 @@ class AttackRunner:
         torch.cuda.synchronize(dev)
         tm["loop_s"] = time.perf_counter() - t1
         tm["units"] = n_units
+        res.timing = tm
+        if not fetch:
+            res.device = dict(was_active=was_active, iter_ids=iter_ids, changed=changed, init_ids=init_ids, latent=ori)
+            return res
         res.n_iter = was_active.sum(0).cpu().numpy().astype(np.int32)
         res.init_ids = init_ids.cpu().numpy()
         res.iter_ids = iter_ids.permute(1, 0, 2).contiguous().cpu().numpy()

@@ -16,6 +16,56 @@ void st_set_error(const char* fmt, ...) {
 extern "C" const char* st_last_error(void) { return g_err; }
 extern "C" int st_abi_version(void) { return 1; }
 
+// ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
+#include <vector>
+struct ProfPair {
+  hipEvent_t a, b;
+  double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfPair> g_prof;       // recorded pairs
+static std::vector<ProfPair> g_prof_free;  // recycled events
+
+extern "C" int st_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return ST_OK;
+}
+extern "C" int st_profile_read(double* gen_ms, double* gen_flops, long long* gen_launches, int reset) {
+  double ms = 0.0, fl = 0.0;
+  for (auto& p : g_prof) {
+    ST_HIP(hipEventSynchronize(p.b));
+    float t = 0.0f;
+    ST_HIP(hipEventElapsedTime(&t, p.a, p.b));
+    ms += t;
+    fl += p.flops;
+  }
+  if (gen_ms) *gen_ms = ms;
+  if (gen_flops) *gen_flops = fl;
+  if (gen_launches) *gen_launches = (long long)g_prof.size();
+  if (reset) {
+    for (auto& p : g_prof) g_prof_free.push_back(p);
+    g_prof.clear();
+  }
+  return ST_OK;
+}
+static int prof_begin(ProfPair* p, double flops, hipStream_t st) {
+  if (!g_prof_free.empty()) {
+    *p = g_prof_free.back();
+    g_prof_free.pop_back();
+  } else {
+    ST_HIP(hipEventCreate(&p->a));
+    ST_HIP(hipEventCreate(&p->b));
+  }
+  p->flops = flops;
+  ST_HIP(hipEventRecord(p->a, st));
+  return ST_OK;
+}
+static int prof_end(ProfPair* p, hipStream_t st) {
+  ST_HIP(hipEventRecord(p->b, st));
+  g_prof.push_back(*p);
+  return ST_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // x[r] = emb[token(s)] * sqrt(d) + pe[pos]   (model.py:126-133 Embeddings, :75-94 PositionalEncoding)
 // one wave per live row; also resets the *next* live counter (ping-pong, see st_decode_greedy).
@@ -263,7 +313,10 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     GemmArgs gg = {};
     gg.X = ws.x; gg.n_dev = n_dev; gg.n_host = n_bound; gg.ln_a = w->lnf_a; gg.ln_b = w->lnf_b;
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
+    ProfPair pp;
+    if (g_prof_on) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
     ST_TRY(launch_panel<EPI_ARGMAX>(gg, n_bound, ST_GEN_SPLITS, st));
+    if (g_prof_on) ST_TRY(prof_end(&pp, st));
     hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, ST_GEN_SPLITS, idx,
                        n_dev, out_ids, top2gap, T, pos, eos, pad, early, pos == T - 1 ? 1 : 0, ws.idx[cur ^ 1],
                        ws.cnt + (cur ^ 1));
