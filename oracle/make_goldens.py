@@ -47,6 +47,12 @@ def run_attack(subset, flags, ckpt, tag, threads):
     siamese, predictor = ref_sc.SiameseNet(256), ref_sc.Predictor(256)
     ref_sc.load_siamese(siamese, predictor, args)
 
+    if not hasattr(ref_sc, "_st_originals"):  # wrappers are re-installed per run around the ORIGINAL functions
+        ref_sc._st_originals = (ref_sc.create_train_data_loader_contrastive, ref_sc.get_contrastive_loss,
+                                ref_sc.contrastive_attack_one)
+    (ref_sc.create_train_data_loader_contrastive, ref_sc.get_contrastive_loss,
+     ref_sc.contrastive_attack_one) = ref_sc._st_originals
+
     lines = []
     ref_sc.print_and_log = lambda s: lines.append(s)
 
@@ -213,7 +219,8 @@ if __name__ == "__main__":
         run_attack(subset, dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "notnll", a.threads)
     elif a.what == "variants":
         sub = [0, 1, 2, 500, 501, 502]
-        run_attack(sub, dict(), ckpt, "nll", a.threads)
+        if not os.path.exists(os.path.join(GOLD, "attack_nll.npz")):
+            run_attack(sub, dict(), ckpt, "nll", a.threads)
         run_attack(sub, dict(just_use_one=True), ckpt, "nll_one", a.threads)
         run_attack(sub, dict(not_nll=True, simplest_siamese=True, pos_victim_lr=0.2, neg_victim_lr=0.3), ckpt, "simplest", a.threads)
         run_attack(sub, dict(not_nll=True, pos_num=3, neg_num=5, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "p3n5", a.threads)

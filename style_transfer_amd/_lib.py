@@ -83,6 +83,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise StError("HIP extension %s is missing; run `python -m style_transfer_amd.build`. "
                           "There is no CPU fallback for the product path." % LIB_PATH)
+        # torch ships its own libamdhip64; load it FIRST so this library binds to the same HIP runtime
+        # instance (streams, device pointers) instead of pulling in a second one from /opt/rocm.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported

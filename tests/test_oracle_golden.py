@@ -1,0 +1,88 @@
+"""CPU: pins the oracle (oracle/st_oracle.py) to golden vectors recorded from the reference itself
+(tests/golden/attack_*.npz, simloss_b128.npz; generator: oracle/make_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, gold
+
+import st_oracle as O  # noqa: E402
+
+
+def test_encoder_latents(ae_sd, gold_notnll):
+    g = gold_notnll
+    idx = np.r_[0:42, 600:642]
+    lat = O.encode_latent(ae_sd, g["enc_src"][idx].astype(np.int64))
+    assert np.abs(lat - g["enc_latent"][idx]).max() < 2e-5 * np.abs(g["enc_latent"]).max()
+
+
+@pytest.mark.parametrize("tag,kw", [("notnll", dict(not_nll=True)), ("nll", dict()), ("nll_one", dict(just_use_one=True)),
+                                    ("simplest", dict(not_nll=True, simplest=True)), ("p3n5", dict(not_nll=True))])
+def test_scorer_loss_grad_adam(scorer_sd, tag, kw):
+    path = os.path.join(GOLD, "attack_%s.npz" % tag)
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g = gold("attack_%s.npz" % tag)
+    ssd, psd = scorer_sd
+    for s in range(min(6, len(g["subset"]))):
+        x = g["init_latent"][s:s + 1]
+        opt = O.Adam((1, 256), float(g["lr"][s]))
+        for it in range(int(g["n_iter"][s])):
+            loss, grad = O.contrastive_loss_and_grad(ssd, psd, x, g["like_latent"][s], g["unlike_latent"][s], 0.1, **kw)
+            assert abs(loss - g["loss"][s, it]) < 2e-5 * max(1, abs(g["loss"][s, it]))
+            assert np.abs(grad[0] - g["grad"][s, it]).max() < 2e-4 * np.abs(g["grad"][s, it]).max()
+            x = opt.step(x, g["grad"][s:s + 1, it])     # reference gradient: isolates the Adam restatement
+            assert np.abs(x[0] - g["latent"][s, it]).max() < 1e-5 * np.abs(g["latent"][s, it]).max()
+
+
+def test_greedy_decode_kv_cache_matches_reference(ae_sd, gold_notnll):
+    g = gold_notnll
+    lat = np.concatenate([g["init_latent"][:12], g["latent"][0, :int(g["n_iter"][0])], g["latent"][40, :int(g["n_iter"][40])]])
+    want = np.concatenate([g["init_ids"][:12], g["ids"][0, :int(g["n_iter"][0])], g["ids"][40, :int(g["n_iter"][40])]])
+    wgap = np.concatenate([g["init_gap"][:12], g["gap"][0, :int(g["n_iter"][0])], g["gap"][40, :int(g["n_iter"][40])]])
+    ids, gap = O.greedy_decode(ae_sd, lat, 60, want_gap=True)
+    for b in range(len(lat)):
+        if not np.array_equal(ids[b], want[b]):
+            first = int(np.nonzero(ids[b] != want[b])[0][0])
+            assert wgap[b, first] < 1e-3
+        else:
+            assert np.abs(gap[b] - wgap[b]).max() < 1e-3
+    ids_e = O.greedy_decode(ae_sd, lat[:6], 60, early_exit=True)
+    for b in range(6):
+        e = next(i for i, t in enumerate(want[b]) if t in (0, 3)) if any(t in (0, 3) for t in want[b]) else 58
+        assert np.array_equal(ids_e[b, :e + 1], want[b, :e + 1]) and (ids_e[b, e + 1:] == 0).all()
+
+
+def test_literal_decode_matches_reference_prefix(ae_sd, gold_notnll):
+    """model.py:271-299 restated line by line (no KV cache), one sentence, first 12 steps"""
+    g = gold_notnll
+    ids = O.greedy_decode_literal(ae_sd, g["init_latent"][1:2], max_len=13)
+    assert np.array_equal(ids[0], g["init_ids"][1, :12])
+
+
+def test_attack_one_reproduces_reference_log(ae_sd, scorer_sd, gold_notnll, id_to_word):
+    """contrastive_attack_one restated: Change./iteration. lines of two sentences equal the reference log"""
+    g = gold_notnll
+    ref = open(os.path.join(GOLD, "attack_notnll_log.txt")).read().split("Sentence Pair.")[1:]
+    ssd, psd = scorer_sd
+    for s in (2, 33):
+        lines = []
+        O.attack_one(ae_sd, ssd, psd, g["init_latent"][s:s + 1], g["like_latent"][s], g["unlike_latent"][s], float(g["lr"][s]),
+                     id_to_word, lines.append, not_nll=True)
+        want = [l.split(" - ", 1)[1] for l in ref[s].splitlines()[1:] if " - " in l]
+        want = [w for w in want[want.index("-" * 40):] if w != "*" * 20]  # drop the next block's headline prefix
+        assert lines == want
+
+
+def test_simloss_oracle_vs_reference_torch():
+    g = gold("simloss_b128.npz")
+    tot = 0
+    for v in range(3):
+        loss, lse = O.simloss(g["ori"], g["like"][v], float(g["tau"]))
+        assert np.abs(loss - g["loss_rows"][v]).max() < 1e-4
+        tot += loss.mean() / 3
+        gw = np.full(128, 1.0 / (3 * 128))
+        do, dl = O.simloss_grads(g["ori"], g["like"][v], gw, float(g["tau"]))
+        assert np.abs(dl - g["d_like"][v]).max() < 1e-3 * np.abs(g["d_like"][v]).max()
+    assert abs(tot - float(g["loss"])) < 1e-5
