@@ -1,0 +1,152 @@
+"""CPU: host-side logic — vocabulary / data loading, packing, log grammar, CLI flags, sharding and the
+world_size-2 gather (gloo)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+
+def test_vocab_and_attack_set(id_to_word):
+    from style_transfer_amd.data import AttackSet, canonical_ids
+    assert len(id_to_word) == 9339 and id_to_word[:4] == ["<PAD>", "<UNK>", "<BOS>", "<EOS>"]
+    assert canonical_ids(id_to_word) is None
+    c = canonical_ids(["a", "b", "a", "c"])
+    assert list(c) == [0, 1, 0, 3]
+    files = [os.path.join(GOLD, "yelp", "neg10_pos10_test%d.json" % i) for i in (0, 1)]
+    d = AttackSet.from_json(files, 9339)
+    assert len(d) == 1000 and d.n_pos == 10 and d.n_neg == 10
+    assert d.labels[:500] == [0] * 500 and d.labels[500:] == [1] * 500
+    assert d.origin[0] == [78, 429, 3797, 83, 975, 527, 14, 34, 57, 1167, 418, 6, 418, 4]
+    d2 = AttackSet.from_json(files, 9339, pos_num=3, neg_num=0)
+    assert d2.n_pos == 3 and d2.n_neg == 0
+    d3 = AttackSet.from_json(files, 100)          # ids >= V -> UNK (data.py:142-143)
+    assert max(max(s) for s in d3.origin) < 100 and 1 in d3.origin[0]
+
+
+def test_encoder_inputs_match_reference_golden(gold_notnll):
+    """the packed encoder inputs equal what the reference's AttackDataLoader fed ae_model.forward"""
+    from style_transfer_amd.data import AttackSet
+    g = gold_notnll
+    files = [os.path.join(GOLD, "yelp", "neg10_pos10_test%d.json" % i) for i in (0, 1)]
+    d = AttackSet.from_json(files, 9339).subset(list(g["subset"]))
+    for s in range(len(d)):
+        rows = g["enc_src"][s * 21:(s + 1) * 21]
+        strip = lambda r: [int(t) for t in r if t != 0]
+        assert strip(rows[0]) == d.origin[s]
+        for j in range(10):
+            assert strip(rows[1 + j]) == d.like[s][j]
+            assert strip(rows[11 + j]) == d.unlike[s][j]
+
+
+def test_pack_sentences():
+    from style_transfer_amd.data import pack_sentences
+    tok, pos, off, mx = pack_sentences([[5, 6, 7], [], [9], [4, 0, 8]])
+    assert tok.tolist() == [5, 6, 7, 9, 4, 8]
+    assert pos.tolist() == [0, 1, 2, 0, 0, 2]       # id 0 inside a sentence: masked position, index kept
+    assert off.tolist() == [0, 3, 3, 4, 6] and mx == 3
+
+
+def test_truncation_to_max_sequence_length():
+    from style_transfer_amd.data import _clip
+    assert len(_clip(list(range(4, 104)), 9339, 1, 60)) == 59
+
+
+def test_id2text_matches_reference_semantics(id_to_word):
+    from style_transfer_amd.data import id2text_sentence
+    assert id2text_sentence([4, 5, 3, 6], id_to_word) == ". the"
+    assert id2text_sentence([4, 0, 6], id_to_word) == "."
+    assert id2text_sentence([4, 99999], id_to_word) == ". <UNK>"
+    assert id2text_sentence([2, 1], id_to_word) == "<BOS> <UNK>"
+
+
+def test_extract_out_equals_get_i_iter_semantics():
+    from style_transfer_amd.logfmt import LOG_PREFIX, extract_out, headline
+    lines = []
+    for s in range(3):
+        lines.append(LOG_PREFIX + headline("Sentence Pair.%d" % s))
+        lines.append(LOG_PREFIX + "Src: x")
+        if s != 1:
+            lines.append(LOG_PREFIX + "Change.0, a%d" % s)
+        lines.append(LOG_PREFIX + "iteration.0, b%d" % s)
+        if s == 2:
+            lines += [LOG_PREFIX + "Change.1, c", LOG_PREFIX + "iteration.1, c", LOG_PREFIX + "Change.2, d", LOG_PREFIX + "Change.3, e"]
+    assert extract_out(lines, pos_c=2, neg_c=2, limit=3) == ["a0\n", "b1\n", "d\n"]
+    assert extract_out(lines, pos_c=0, neg_c=0, limit=3) == ["a0\n", "b1\n", "a2\n"]
+    assert extract_out(lines, it=0, limit=3) == ["b0\n", "b1\n", "b2\n"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/outputs/get_i_iter.py"), reason="reference script not on this box")
+def test_reference_get_i_iter_runs_unchanged_on_our_log_format(tmp_path):
+    """outputs/get_i_iter.py (with an inert `fasttext` stub module on the path — it imports it but never
+    uses it) parses the golden log and our extractor agrees with it."""
+    from style_transfer_amd.logfmt import extract_out
+    (tmp_path / "fasttext.py").write_text("")
+    log = os.path.join(GOLD, "attack_notnll_log.txt")
+    out = tmp_path / "out"
+    env = dict(os.environ, PYTHONPATH=str(tmp_path))
+    subprocess.check_call([sys.executable, "/root/reference/outputs/get_i_iter.py", "--file", log, "--out", str(out),
+                           "--pos_c", "2", "--neg_c", "2", "--partial"], env=env, stdout=subprocess.DEVNULL)
+    ref = open(out).readlines()
+    mine = extract_out(open(log).read().splitlines(), 2, 2, limit=50)
+    assert ref == mine
+
+
+def test_cli_flags_and_defaults_match_main_py():
+    from style_transfer_amd.main import build_parser
+    a = build_parser().parse_args(["--attack", "--not_nll", "--pos_victim_lr=0.2", "--neg_victim_lr=0.2"])
+    assert (a.id_pad, a.id_unk, a.id_bos, a.id_eos) == (0, 1, 2, 3)
+    assert a.task == "yelp" and a.word_dict_max_num == 5 and a.batch_size == 128 and a.max_sequence_length == 60
+    assert (a.num_layers_AE, a.transformer_model_size, a.transformer_ff_size, a.latent_size) == (2, 256, 1024, 256)
+    assert a.tau == 0.1 and a.victim_optimizer == "Adam" and a.victim_lr == 0.25
+    assert a.attack_max_iter == 18 and a.attack_max_change == 7
+    assert a.pos_num is None and a.neg_num is None and a.pos_victim_lr == 0.2 and a.neg_victim_lr == 0.2
+    assert a.attack and a.not_nll and not (a.simplest_siamese or a.reverse_order or a.just_use_one or a.retext or a.dance)
+
+
+def test_shard_range_covers_everything():
+    from style_transfer_amd.main import shard_range
+    for n in (0, 1, 7, 1000, 1001):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+GATHER_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from style_transfer_amd.main import gather_results, shard_range
+from style_transfer_amd.attack import AttackResult
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+S, I, T = 11, 18, 59
+rng = np.random.default_rng(0)
+full = AttackResult(rng.integers(0, 19, S).astype(np.int32), rng.integers(0, 9000, (S, T)).astype(np.int32),
+                    rng.integers(0, 9000, (S, I, T)).astype(np.int32), rng.integers(0, 2, (S, I)).astype(np.uint8),
+                    rng.integers(0, 9000, (S, 10, T)).astype(np.int32), None)
+lo, hi = shard_range(S, rank, world)
+mine = AttackResult(full.n_iter[lo:hi], full.init_ids[lo:hi], full.iter_ids[lo:hi], full.changed[lo:hi], full.like_ids[lo:hi], None)
+got = gather_results(mine, world, torch.device("cpu"))
+for f in ("n_iter", "init_ids", "iter_ids", "changed", "like_ids"):
+    assert np.array_equal(getattr(got, f), getattr(full, f)), f
+assert got.unlike_ids is None
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_gather_reassembles_global_order(tmp_path):
+    """N > 1 path: contiguous shards, all_gather of ragged per-shard records, global order restored (gloo)."""
+    script = tmp_path / "w.py"
+    script.write_text(GATHER_WORKER % dict(root=ROOT))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
