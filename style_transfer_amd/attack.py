@@ -50,6 +50,8 @@ class AttackConfig:
     log_decodes: bool = True       # the 1+10+10 decodes behind the Rec:/Sim:/Ref: log lines
     want_gap: bool = False
     want_trace: bool = False       # keep latents / grads / losses per iteration (parity tests)
+    iters_per_decode: int = 6      # edit iterations whose latents are decoded together as one batch
+    count_units: bool = False
 
     @classmethod
     def from_namespace(cls, ns, **over):
@@ -135,14 +137,11 @@ class AttackRunner:
         like_z = ops.scorer_embed(self.scorer, like_lat).view(B, kp, 256) if kp else None
         unlike_z = ops.scorer_embed(self.scorer, unlike_lat).view(B, kn, 256) if kn else None
         res = AttackResult(None, None, None, None)
-        if c.log_decodes:
-            all_ids, _, _ = self.decode(lat_all)
-            init_ids = all_ids[:B].clone()
-            res.like_ids = all_ids[B:B + B * kp].view(B, kp, T).cpu().numpy() if kp else None
-            res.unlike_ids = all_ids[B + B * kp:].view(B, kn, T).cpu().numpy() if kn else None
-            init_gap = None
-        else:
-            init_ids, init_gap, _ = self.decode(ori, want_gap=c.want_gap)
+        like_ids_dev = unlike_ids_dev = None
+        if c.log_decodes and (kp or kn):
+            ref_ids, _, _ = self.decode(lat_all[B:])
+            like_ids_dev = ref_ids[:B * kp].view(B, kp, T) if kp else None
+            unlike_ids_dev = ref_ids[B * kp:].view(B, kn, T) if kn else None
         gidx = global_index if torch.is_tensor(global_index) else torch.as_tensor(np.asarray(global_index), device=dev)
         lr = torch.where(gidx < 500, torch.tensor(c.pos_victim_lr, device=dev), torch.tensor(c.neg_victim_lr, device=dev)).float().contiguous()
         m = torch.zeros(B, 256, device=dev)
@@ -152,51 +151,78 @@ class AttackRunner:
         n_changes = torch.zeros(B, dtype=torch.int32, device=dev)
         changed = torch.zeros(I, B, dtype=torch.uint8, device=dev)
         was_active = torch.zeros(I, B, dtype=torch.uint8, device=dev)
-        acc_ids = init_ids.clone()
         iter_ids = torch.zeros(I, B, T, dtype=torch.int32, device=dev)
         new_ids = torch.zeros(B, T, dtype=torch.int32, device=dev)
+        final_latent = ori.clone()
+        init_ids = acc_ids = init_gap = None
+        want_gap = c.want_gap or c.want_trace
         tr = {k: [] for k in ("latent", "grad", "loss", "ids", "gap")} if c.want_trace else None
         max_change = (1 << 30) if c.dance else c.attack_max_change
+        C = max(1, min(c.iters_per_decode, I))
         torch.cuda.synchronize(dev)
         tm["setup_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()
         n_units = 0
-        for it in range(I):
+        # The latent trajectory x_0 -> x_1 -> ... does not depend on the decodes (they only feed the change
+        # counter and the stop rule, siamese_contrastive.py:812-839), so C edit steps are taken first and
+        # their C latents (plus x_0 in the first round) are decoded as ONE batch; the change bookkeeping
+        # then replays the iterations in order.  Iterations past a sentence's stop point are discarded.
+        for it0 in range(0, I, C):
             live = torch.nonzero(active, as_tuple=False).flatten()
             n_live = int(live.numel())
             if n_live == 0:
                 break
-            n_units += n_live
-            was_active[it] = active
-            loss, grad = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, active, tau=c.tau,
-                                              not_nll=c.not_nll, simplest=c.simplest_siamese,
-                                              just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
-                                              want_grad=c.want_trace)
-            if n_live == B:
-                ids, gap, _ = self.decode(ori, want_gap=c.want_gap or c.want_trace)
-                new_ids.copy_(ids)
-            else:
-                ids, gap, _ = self.decode(ori.index_select(0, live).contiguous(), want_gap=c.want_gap or c.want_trace)
-                new_ids.index_copy_(0, live, ids)
-            ops.accept_changes(new_ids, acc_ids, self.ae.vocab, n_changes, changed[it], active, max_change=max_change,
-                               unk=c.id_unk, eos=c.id_eos, pad=c.id_pad, canon=self.canon, rec_ids=iter_ids[it])
-            if tr is not None:
-                g_full = torch.zeros(B, T, device=dev)
-                g_full.index_copy_(0, live, gap) if n_live != B else g_full.copy_(gap)
-                for k, t in (("latent", ori), ("grad", grad), ("loss", loss), ("ids", new_ids), ("gap", g_full)):
-                    tr[k].append(t.detach().cpu().numpy().copy())
+            cn = min(C, I - it0)
+            snaps = [ori.index_select(0, live)] if it0 == 0 else []
+            for j in range(cn):
+                loss, grad = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, active, tau=c.tau,
+                                                  not_nll=c.not_nll, simplest=c.simplest_siamese,
+                                                  just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
+                                                  want_grad=c.want_trace)
+                snaps.append(ori.index_select(0, live))
+                if tr is not None:
+                    tr["latent"].append(ori.detach().cpu().numpy().copy())
+                    tr["grad"].append(grad.cpu().numpy())
+                    tr["loss"].append(loss.cpu().numpy())
+            ids, gap, _ = self.decode(torch.cat(snaps, 0), want_gap=want_gap)
+            ids = ids.view(len(snaps), n_live, T)
+            gap = gap.view(len(snaps), n_live, T) if gap is not None else None
+            k0 = 0
+            if it0 == 0:
+                init_ids = torch.zeros(B, T, dtype=torch.int32, device=dev)
+                init_ids.index_copy_(0, live, ids[0])
+                acc_ids = init_ids.clone()
+                if gap is not None:
+                    init_gap = torch.zeros(B, T, device=dev).index_copy_(0, live, gap[0])
+                k0 = 1
+            for j in range(cn):
+                it = it0 + j
+                was_active[it] = active
+                n_units += int(active.sum().item()) if c.count_units else 0
+                new_ids.index_copy_(0, live, ids[k0 + j])
+                still = active.bool()
+                final_latent[live] = torch.where(still[live, None], snaps[k0 + j], final_latent[live])
+                ops.accept_changes(new_ids, acc_ids, self.ae.vocab, n_changes, changed[it], active, max_change=max_change,
+                                   unk=c.id_unk, eos=c.id_eos, pad=c.id_pad, canon=self.canon, rec_ids=iter_ids[it])
+                if tr is not None:
+                    tr["ids"].append(new_ids.cpu().numpy().copy())
+                    tr["gap"].append(torch.zeros(B, T, device=dev).index_copy_(0, live, gap[k0 + j]).cpu().numpy())
+        if not c.count_units:
+            n_units = int(was_active.sum().item())
         torch.cuda.synchronize(dev)
         tm["loop_s"] = time.perf_counter() - t1
         tm["units"] = n_units
         res.timing = tm
         if not fetch:
-            res.device = dict(was_active=was_active, iter_ids=iter_ids, changed=changed, init_ids=init_ids, latent=ori)
+            res.device = dict(was_active=was_active, iter_ids=iter_ids, changed=changed, init_ids=init_ids, latent=final_latent)
             return res
         res.n_iter = was_active.sum(0).cpu().numpy().astype(np.int32)
         res.init_ids = init_ids.cpu().numpy()
         res.iter_ids = iter_ids.permute(1, 0, 2).contiguous().cpu().numpy()
         res.changed = changed.t().contiguous().cpu().numpy()
-        res.final_latent = ori.cpu().numpy()
+        res.final_latent = final_latent.cpu().numpy()
+        res.like_ids = None if like_ids_dev is None else like_ids_dev.cpu().numpy()
+        res.unlike_ids = None if unlike_ids_dev is None else unlike_ids_dev.cpu().numpy()
         if tr is not None:
             res.trace = {k: np.stack(vv, 1) if vv else None for k, vv in tr.items()}
             res.trace["init_gap"] = None if init_gap is None else init_gap.cpu().numpy()
