@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
     ap.add_argument("--fixed-steps", action="store_true", help="no early exit at EOS: always 59 decode steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--iters-per-decode", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -89,7 +90,8 @@ def main():
     ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors")), dev)
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
                              W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
-    cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, early_exit=not a.fixed_steps)
+    cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, early_exit=not a.fixed_steps,
+                       iters_per_decode=a.iters_per_decode)
     runner = AttackRunner(ae, scorer, cfg, dev)
     B = a.batch
     data = AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank)
@@ -107,10 +109,13 @@ def main():
     sync()
     L.st_profile_enable(1)
     units = 0
+    setup_s = loop_s = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         r = runner.run_prepared(prep, gidx, fetch=False)
         units += r.timing["units"]
+        setup_s += r.timing["setup_s"]
+        loop_s += r.timing["loop_s"]
     sync()
     dt = time.perf_counter() - t0
     L.st_profile_enable(0)
@@ -135,6 +140,8 @@ def main():
                                    % (a.shape, B, "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS"),
                        "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
                        "mean_edit_iterations_per_sentence": n_iter_mean,
+                       "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
+                       "iters_per_decode": cfg.iters_per_decode,
                        "edit_iteration_units_per_s": world * units / dt},
             "roofline": {"bound": "mfma", "kernel": "panel_gemm_kernel<EPI_ARGMAX> (generator GEMM + argmax)",
                          "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

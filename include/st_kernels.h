@@ -45,6 +45,14 @@ const char* st_last_error(void);
 int st_profile_enable(int on);
 int st_profile_read(double* gen_ms, double* gen_flops, long long* gen_launches, int reset);
 
+/* Weight packing (no reference counterpart).  The GEMM kernels read nn.Linear weight matrices
+ * W [N,K] row-major in MFMA-fragment order so that every wave load is one coalesced 1 KiB read:
+ *   packed[((blk*(K/8) + kg)*64 + lane)*4 + j] = W[blk*32 + (lane&31)][kg*8 + 4*(lane>>5) + j]
+ * (rows >= N are zero).  Fields documented as "packed" below must point at such an image; pack once
+ * at load time.  st_packed_weight_floats gives the image size in floats.                         */
+size_t st_packed_weight_floats(int N, int K);
+int st_pack_weight(const float* W, int N, int K, float* out_packed, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (1) Style scorer: SiameseNet + Predictor + contrastive score + backward-to-latent + Adam.
  * ------------------------------------------------------------------------------------------- */
@@ -106,7 +114,7 @@ typedef struct StDecoderWeights {
   const float* emb;                    /* tgt_embed.0.lut.weight [V,256]                        */
   const float* pe;                     /* tgt_embed.1.pe [pe_rows,256]                          */
   const float *lnf_a, *lnf_b;          /* decoder.norm                                          */
-  const float *gen_w, *gen_b;          /* generator.proj [V,256], [V]                           */
+  const float *gen_w, *gen_b;          /* generator.proj [V,256] PACKED (st_pack_weight), [V]   */
   StDecLayer layer[ST_MAX_LAYERS];
 } StDecoderWeights;
 
@@ -132,7 +140,7 @@ int st_decode_greedy(const StDecoderWeights* w, const float* latent, int B, int 
 /* ---------------------------------------------------------------------------------------------
  * (3) Generator GEMM + argmax: ids[r] = argmax_v( LN(h[r]) . W[v] + b[v] )  (model.py:200-207 +
  * torch.max(prob, dim=1), :290-292; log_softmax is argmax-invariant and skipped; ties -> lowest
- * index).  ln_a/ln_b may be NULL (no LayerNorm).  scratch: n*ST_ARGMAX_SPLITS*16 bytes.          */
+ * index).  W is PACKED (st_pack_weight).  ln_a/ln_b may be NULL.  scratch: n*ST_ARGMAX_SPLITS*16 bytes. */
 #define ST_ARGMAX_SPLITS 4
 int st_gemm_argmax(const float* h, const float* ln_a, const float* ln_b, const float* W,
                    const float* b, int n, int V, int32_t* ids, float* best, float* gap,

@@ -52,6 +52,8 @@ EXPORTS = {
     "st_last_error": (C.c_char_p, []),
     "st_profile_enable": (C.c_int, [C.c_int]),
     "st_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
+    "st_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "st_pack_weight": (C.c_int, [fp, C.c_int, C.c_int, fp, fp]),
     "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
     "st_scorer_edit_step": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                       C.c_int, C.c_float, C.c_int, fp, fp, fp]),

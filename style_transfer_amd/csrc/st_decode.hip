@@ -2,7 +2,7 @@
 // EncoderDecoder.greedy_decode, /root/reference/method/yelp/model.py:271-299, which re-runs the whole
 // decoder over the growing prefix at every step) + generator GEMM with fused argmax (model.py:200-207,
 // :290-292).  One launch sequence per decode step over the COMPACTED list of live sentences.
-#include "st_gemm.h"
+#include "st_rowpanel.h"
 
 #include <stdarg.h>
 
@@ -222,7 +222,7 @@ static int check_weights(const StDecoderWeights* w, int max_len) {
   ST_CHECK_ARG(w != nullptr, "weights struct is NULL");
   ST_CHECK_ARG(w->d_model == ST_D, "d_model=%d unsupported (kernels are specialised for %d)", w->d_model, ST_D);
   ST_CHECK_ARG(w->n_heads == 4, "n_heads=%d unsupported (4)", w->n_heads);
-  ST_CHECK_ARG(w->d_ff > 0 && w->d_ff % 32 == 0, "d_ff=%d must be a positive multiple of 32", w->d_ff);
+  ST_CHECK_ARG(w->d_ff > 0 && w->d_ff % 256 == 0, "d_ff=%d must be a positive multiple of 256", w->d_ff);
   ST_CHECK_ARG(w->n_layers >= 1 && w->n_layers <= ST_MAX_LAYERS, "n_layers=%d out of range", w->n_layers);
   ST_CHECK_ARG(w->vocab >= 4, "vocab=%d too small", w->vocab);
   ST_CHECK_ARG(max_len >= 2 && max_len - 1 <= 64, "max_len=%d unsupported (decode length max_len-1 must be <= 64)", max_len);
@@ -271,9 +271,9 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     GemmArgs g = {};
     g.X = latent; g.n_host = B; g.W = w->layer[l].xv_w; g.bias = w->layer[l].xv_b; g.N = 256;
     g.out = ws.att; g.ldo = 256;
-    ST_TRY(launch_panel<EPI_BIAS>(g, B, 1, st));
+    ST_TRY(launch_rp<EPI_BIAS>(g, B, 1, st));
     g.X = ws.att; g.W = w->layer[l].xo_w; g.bias = w->layer[l].xo_b; g.out = ws.cc + (size_t)l * B * 256;
-    ST_TRY(launch_panel<EPI_BIAS>(g, B, 1, st));
+    ST_TRY(launch_rp<EPI_BIAS>(g, B, 1, st));
   }
 
   int n_bound = B;
@@ -293,29 +293,29 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
-      ST_TRY(launch_panel<EPI_QKV>(g, n_bound, 3, st));
+      ST_TRY(launch_rp<EPI_QKV>(g, n_bound, 3, st));
       hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
                          ws.att);
       ST_LAUNCH_CHECK();
       GemmArgs o = {};
       o.X = ws.att; o.n_dev = n_dev; o.n_host = n_bound; o.W = y.wo; o.bias = y.bo; o.N = 256;
       o.out = ws.x; o.ldo = 256; o.resid = ws.x; o.cconst = ws.cc + (size_t)l * B * 256; o.ld_cc = 256; o.idx = idx;
-      ST_TRY(launch_panel<EPI_RESID>(o, n_bound, 1, st));
+      ST_TRY(launch_rp<EPI_RESID>(o, n_bound, 1, st));
       GemmArgs f1 = {};
       f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
       f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
-      ST_TRY(launch_panel<EPI_RELU>(f1, n_bound, (w->d_ff + 255) / 256, st));
+      ST_TRY(launch_rp<EPI_RELU>(f1, n_bound, (w->d_ff + 255) / 256, st));
       GemmArgs f2 = {};
       f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
       f2.out = ws.x; f2.ldo = 256; f2.resid = ws.x;
-      ST_TRY(launch_kloop<EPI_RESID>(f2, n_bound, st));
+      ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, n_bound, st));
     }
     GemmArgs gg = {};
     gg.X = ws.x; gg.n_dev = n_dev; gg.n_host = n_bound; gg.ln_a = w->lnf_a; gg.ln_b = w->lnf_b;
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
     ProfPair pp;
     if (g_prof_on) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
-    ST_TRY(launch_panel<EPI_ARGMAX>(gg, n_bound, ST_GEN_SPLITS, st));
+    ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, ST_GEN_SPLITS, st));
     if (g_prof_on) ST_TRY(prof_end(&pp, st));
     hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, ST_GEN_SPLITS, idx,
                        n_dev, out_ids, top2gap, T, pos, eos, pad, early, pos == T - 1 ? 1 : 0, ws.idx[cur ^ 1],
@@ -344,9 +344,20 @@ extern "C" int st_gemm_argmax(const float* h, const float* ln_a, const float* ln
   GemmArgs gg = {};
   gg.X = h; gg.n_host = n; gg.ln_a = ln_a; gg.ln_b = ln_b; gg.W = W; gg.bias = b; gg.N = V;
   gg.partial = (float4*)scratch;
-  ST_TRY(launch_panel<EPI_ARGMAX>(gg, n, ST_ARGMAX_SPLITS, st));
+  ST_TRY(launch_rp<EPI_ARGMAX>(gg, n, ST_ARGMAX_SPLITS, st));
   hipLaunchKernelGGL(argmax_merge_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float4*)scratch,
                      ST_ARGMAX_SPLITS, n, ids, best, gap);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+extern "C" size_t st_packed_weight_floats(int N, int K) { return (N > 0 && K > 0 && K % 8 == 0) ? rp_packed_floats(N, K) : 0; }
+
+extern "C" int st_pack_weight(const float* W, int N, int K, float* out, void* stream) {
+  ST_CHECK_ARG(W && out, "NULL buffer");
+  ST_CHECK_ARG(N > 0 && K > 0 && K % 8 == 0, "N=%d K=%d (K must be a positive multiple of 8)", N, K);
+  const size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
+  hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, N, K, out);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

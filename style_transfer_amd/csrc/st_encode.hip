@@ -4,7 +4,7 @@
 // Rows = non-pad tokens of all sentences, packed back to back: padding never enters a product
 // (pad keys are masked to exp(-1e9)=0 in the reference and pad positions are dropped from the
 // latent sum by src_mask, model.py:240), so the packed result equals the padded one.
-#include "st_gemm.h"
+#include "st_rowpanel.h"
 
 __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
                                                         const int32_t* __restrict__ tok, const int32_t* __restrict__ pos,
@@ -90,7 +90,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
                                 void* workspace, size_t workspace_bytes, void* stream) {
   ST_CHECK_ARG(w != nullptr, "weights struct is NULL");
   ST_CHECK_ARG(w->d_model == ST_D && w->n_heads == 4, "d_model=%d n_heads=%d unsupported (256, 4)", w->d_model, w->n_heads);
-  ST_CHECK_ARG(w->d_ff > 0 && w->d_ff % 32 == 0, "d_ff=%d must be a positive multiple of 32", w->d_ff);
+  ST_CHECK_ARG(w->d_ff > 0 && w->d_ff % 256 == 0, "d_ff=%d must be a positive multiple of 256", w->d_ff);
   ST_CHECK_ARG(w->n_layers >= 1 && w->n_layers <= ST_MAX_LAYERS, "n_layers=%d", w->n_layers);
   ST_CHECK_ARG(n_rows >= 0 && n_sent >= 0, "n_rows=%d n_sent=%d", n_rows, n_sent);
   ST_CHECK_ARG(max_sent_len <= 64 && max_sent_len <= w->pe_rows, "max_sent_len=%d unsupported (<= 64 and <= pe_rows)", max_sent_len);
@@ -122,19 +122,19 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     GemmArgs g = {};
     g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
     g.out = qkv; g.ldo = 768;
-    ST_TRY(launch_panel<EPI_BIAS>(g, R, 3, st));
+    ST_TRY(launch_rp<EPI_BIAS>(g, R, 3, st));
     hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
     ST_LAUNCH_CHECK();
     GemmArgs o = {};
     o.X = att; o.n_host = R; o.W = y.wo; o.bias = y.bo; o.N = 256; o.out = x; o.ldo = 256; o.resid = x;
-    ST_TRY(launch_panel<EPI_RESID>(o, R, 1, st));
+    ST_TRY(launch_rp<EPI_RESID>(o, R, 1, st));
     GemmArgs f1 = {};
     f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
     f1.out = h; f1.ldo = w->d_ff;
-    ST_TRY(launch_panel<EPI_RELU>(f1, R, (w->d_ff + 255) / 256, st));
+    ST_TRY(launch_rp<EPI_RELU>(f1, R, (w->d_ff + 255) / 256, st));
     GemmArgs f2 = {};
     f2.X = h; f2.n_host = R; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256; f2.out = x; f2.ldo = 256; f2.resid = x;
-    ST_TRY(launch_kloop<EPI_RESID>(f2, R, st));
+    ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, R, st));
   }
   hipLaunchKernelGGL(enc_latent_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, x, sent_off, n_sent, w->lnf_a, w->lnf_b, latent);
   ST_LAUNCH_CHECK();

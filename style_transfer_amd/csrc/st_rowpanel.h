@@ -1,0 +1,348 @@
+// Row-panel f32-MFMA GEMM, barrier-free main loop:  C[n,N] = op(X[n,256]) . W[N,256]^T (+ epilogue)
+//
+// One 256-thread workgroup owns a 64-row panel of X, resident in LDS (optionally LayerNorm'ed in
+// place); LDS = 69 KiB so two workgroups share a CU.  Each of the 4 waves walks its OWN 32-column
+// blocks of W (blocks wave, wave+4, ... of the workgroup's column range) and never shares W data with
+// another wave, so W needs no LDS staging and the main loop needs no barrier: B fragments are loaded
+// straight from global memory (L2-resident weights) into VGPRs through an 8-deep register ring.
+// W is pre-packed by st_pack_weight into fragment order [block][kg][lane][4] so that every wave load
+// is one fully coalesced 1 KiB read:
+//     packed[((blk*(K/8) + kg)*64 + lane)*4 + j] = W[blk*32 + (lane&31)][kg*8 + 4*(lane>>5) + j]
+// (the lane<->k permutation of st_gemm.h).  A fragments come from the LDS panel (conflict-free b128).
+#pragma once
+#include "st_gemm.h"
+
+#define RP_LDS ((64 * ST_LDA + 4 * 64 * 4) * 4)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                  // [64][ST_LDA]
+  float* red = smem + 64 * ST_LDA;   // [4 waves][64 rows][4]
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // ---- X panel -> LDS (64 rows x 64 float4, 16 per thread), optional LayerNorm ----
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int f = tid + i * 256;
+    const int r = f >> 6, c4 = f & 63;
+    *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+  }
+  __syncthreads();
+  if (a.ln_a) {
+    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      float* p = As + (wave * 16 + rr) * ST_LDA + lane * 4;
+      *(f32x4*)p = layernorm256(*(f32x4*)p, ga, gb);
+    }
+    __syncthreads();
+  }
+
+  Top2 best[2][16];
+  Lse run[2][16];
+  float tgt[2][16];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (EPI == EPI_ARGMAX) {
+        best[mi][r].m1 = -INFINITY;
+        best[mi][r].i1 = 0x7fffffff;
+        best[mi][r].m2 = -INFINITY;
+      }
+      if (EPI == EPI_LSE) {
+        run[mi][r].m = -INFINITY;
+        run[mi][r].l = 0.0f;
+        tgt[mi][r] = 0.0f;
+      }
+    }
+
+  // this workgroup's column blocks [b0, b1), this wave's: b0 + wave + 4*i
+  const int nblk = (a.N + 31) >> 5;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per;
+  const int b1 = min(nblk, b0 + per);
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) >> 2 : 0;
+  const int total = cnt * 32;  // (block, kg) steps
+  const float* Wl = a.W + (size_t)lane * 4;
+  auto wload = [&](int g) -> f32x4 {
+    g = min(g, total - 1);
+    const int blk = b0 + wave + 4 * (g >> 5);
+    return *(const f32x4*)(Wl + ((size_t)blk * 32 + (g & 31)) * 256);
+  };
+  f32x4 ring[8];
+  if (total > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ring[j] = wload(j);
+  }
+  const float* Ab = As + l31 * ST_LDA + 4 * half;
+  f32x16 acc0 = {0}, acc1 = {0};
+  for (int g0 = 0; g0 < total; g0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kg = (g0 + j) & 31;
+      const f32x4 b = ring[j];
+      ring[j] = wload(g0 + j + 8);
+      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+      const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc0 = mfma32(a0[s], b[s], acc0);
+        acc1 = mfma32(a1[s], b[s], acc1);
+      }
+    }
+    if (((g0 + 8) & 31) == 0) {
+      // ---- epilogue for this wave's column block ----
+      const int col = ((b0 + wave + 4 * (g0 >> 5)) << 5) + l31;
+      const bool colok = col < a.N;
+      const float bv = (colok && a.bias) ? a.bias[col] : 0.0f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x16 acc = mi ? acc1 : acc0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + mi * 32 + mfma32_row(r, lane);
+          float v = acc[r] + bv;
+          if (EPI == EPI_ARGMAX) {
+            v = colok ? v : -INFINITY;
+            Top2& t = best[mi][r];
+            const bool gt = v > t.m1;
+            t.m2 = gt ? t.m1 : fmaxf(t.m2, v);
+            t.i1 = gt ? col : t.i1;
+            t.m1 = gt ? v : t.m1;
+          } else if (EPI == EPI_LSE) {
+            if (colok) {
+              const float sv = v * a.scale;
+              Lse& u = run[mi][r];
+              const float mn = fmaxf(u.m, sv);
+              u.l = u.l * expf(u.m - mn) + expf(sv - mn);
+              u.m = mn;
+              if (col == a.row_offset + row) tgt[mi][r] = sv;
+            }
+          } else if (row < n && colok) {
+            if (EPI == EPI_BIAS) {
+              a.out[(size_t)row * a.ldo + col] = v;
+            } else if (EPI == EPI_RELU) {
+              a.out[(size_t)row * a.ldo + col] = fmaxf(v, 0.0f);
+            } else if (EPI == EPI_RESID) {
+              v += a.resid[(size_t)row * a.ldo + col];
+              if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
+              a.out[(size_t)row * a.ldo + col] = v;
+            } else if (EPI == EPI_DS) {
+              const float sv = v * a.scale;
+              const float pr = expf(sv - a.lse[row]) - (col == a.row_offset + row ? 1.0f : 0.0f);
+              a.out[(size_t)row * a.ldo + col] = a.g[row] * pr * a.scale;
+            } else if (EPI == EPI_QKV) {
+              if (col < 256) {
+                a.q[(size_t)row * 256 + col] = v;
+              } else {
+                const long s = a.idx[row];
+                float* base = (col < 512) ? a.kbase : a.vbase;
+                base[s * a.kv_stride + ((col - 256) & 255)] = v;
+              }
+            }
+          }
+        }
+      }
+      acc0 = (f32x16){0};
+      acc1 = (f32x16){0};
+    }
+  }
+
+  if (EPI == EPI_ARGMAX || EPI == EPI_LSE) {
+    // reduce each (mi, reg) row over the 32 lanes of its half, then over the 4 waves through LDS
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* p = red + (wave * 64 + mi * 32 + mfma32_row(r, lane)) * 4;
+        if (EPI == EPI_ARGMAX) {
+          Top2 t = best[mi][r];
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            Top2 u;
+            u.m1 = __shfl_xor(t.m1, o, 64);
+            u.i1 = __shfl_xor(t.i1, o, 64);
+            u.m2 = __shfl_xor(t.m2, o, 64);
+            t = top2_merge(t, u);
+          }
+          if (l31 == 0) {
+            p[0] = t.m1;
+            p[1] = __int_as_float(t.i1);
+            p[2] = t.m2;
+          }
+        } else {
+          Lse t = run[mi][r];
+          float tg = tgt[mi][r];
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            Lse u;
+            u.m = __shfl_xor(t.m, o, 64);
+            u.l = __shfl_xor(t.l, o, 64);
+            t = lse_merge(t, u);
+            tg += __shfl_xor(tg, o, 64);
+          }
+          if (l31 == 0) {
+            p[0] = t.m;
+            p[1] = t.l;
+            p[2] = tg;
+          }
+        }
+      }
+    __syncthreads();
+    if (tid < 64 && m0 + tid < n) {
+      if (EPI == EPI_ARGMAX) {
+        Top2 t = {red[tid * 4 + 0], __float_as_int(red[tid * 4 + 1]), red[tid * 4 + 2]};
+        for (int w = 1; w < 4; ++w) {
+          Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
+          t = top2_merge(t, u);
+        }
+        a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, 0.0f);
+      } else {
+        Lse t = {red[tid * 4 + 0], red[tid * 4 + 1]};
+        float tg = red[tid * 4 + 2];
+        for (int w = 1; w < 4; ++w) {
+          Lse u = {red[(w * 64 + tid) * 4 + 0], red[(w * 64 + tid) * 4 + 1]};
+          t = lse_merge(t, u);
+          tg += red[(w * 64 + tid) * 4 + 2];
+        }
+        a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m, t.l, tg, 0.0f);
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  dim3 grid((n_bound + 63) / 64, splits);
+  hipLaunchKernelGGL(rp_gemm_kernel<EPI>, grid, dim3(256), RP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K > 256 with N == 256 (feed_forward.w_2: K = d_ff): the X panel is walked in 256-wide K chunks
+// (reloaded into LDS between two barriers), the whole [64,256] output stays in accumulators
+// (wave w owns column blocks w and w+4: 2 blocks x 2 row tiles = 64 registers).  Epilogue: BIAS/RESID.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int K = a.K, kgs = K >> 3, nchunk = K >> 8;
+  const float* W0 = a.W + ((size_t)wave * kgs) * 256 + (size_t)lane * 4;        // block `wave`
+  const float* W1 = a.W + ((size_t)(wave + 4) * kgs) * 256 + (size_t)lane * 4;  // block `wave + 4`
+  const int total = kgs;
+  f32x4 r0[4], r1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r0[j] = *(const f32x4*)(W0 + (size_t)min(j, total - 1) * 256);
+    r1[j] = *(const f32x4*)(W1 + (size_t)min(j, total - 1) * 256);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+  const float* Ab = As + l31 * ST_LDA + 4 * half;
+  for (int c = 0; c < nchunk; ++c) {
+    if (c) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 6, c4 = f & 63;
+      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * K + c * 256 + c4 * 4);
+    }
+    __syncthreads();
+    for (int g0 = 0; g0 < 32; g0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kg = g0 + j;
+        const f32x4 b0 = r0[j], b1 = r1[j];
+        const int nx = min(c * 32 + kg + 4, total - 1);
+        r0[j] = *(const f32x4*)(W0 + (size_t)nx * 256);
+        r1[j] = *(const f32x4*)(W1 + (size_t)nx * 256);
+        const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+        const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
+          acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
+          acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
+          acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int col = (wave + 4 * nb) * 32 + l31;
+    const float bv = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + mi * 32 + mfma32_row(r, lane);
+        if (row >= n) continue;
+        float v = acc[mi][nb][r] + bv;
+        if (EPI == EPI_RESID) {
+          v += a.resid[(size_t)row * a.ldo + col];
+          if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
+        }
+        a.out[(size_t)row * a.ldo + col] = v;
+      }
+  }
+}
+
+template <int EPI>
+static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)rp_kchunk_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  if (a.N != 256 || a.K % 256 != 0 || a.K <= 0) {
+    st_set_error("rp_kchunk: needs N == 256 and K a multiple of 256 (N=%d K=%d)", a.N, a.K);
+    return ST_EINVAL;
+  }
+  hipLaunchKernelGGL(rp_kchunk_kernel<EPI>, dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+// packed-weight helpers -------------------------------------------------------------------------
+static inline size_t rp_packed_floats(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ W, int N, int K,
+                                                          float* __restrict__ out) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the packed image
+  const int kgs = K >> 3;
+  const size_t total = (size_t)((N + 31) / 32) * kgs * 64;
+  if (o >= total) return;
+  const int lane = (int)(o & 63);
+  const int kg = (int)((o >> 6) % kgs);
+  const int blk = (int)((o >> 6) / kgs);
+  const int row = blk * 32 + (lane & 31);
+  f32x4 v = {0, 0, 0, 0};
+  if (row < N) v = *(const f32x4*)(W + (size_t)row * K + kg * 8 + 4 * (lane >> 5));
+  *(f32x4*)(out + o * 4) = v;
+}

@@ -7,7 +7,7 @@
 //   bwd: dS is produced in row chunks of <= 1024 rows (<= 32 MiB at Bk = 8192: Infinity-Cache
 //        resident) by recomputing S from the saved logsumexp, and consumed at once by two GEMMs:
 //        d_ou = dS . ku   and   d_ku += dS^T . ou.
-#include "st_gemm.h"
+#include "st_rowpanel.h"
 
 #define SL_SPLITS 4
 #define SL_CHUNK 1024
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void unit_rows_bwd_kernel(const float* __restr
 static inline size_t sl_align(size_t v) { return (v + 255) / 256 * 256; }
 
 struct SlWs {
-  float *ou, *ku, *kut, *on, *kn, *dou, *dku, *ds;
+  float *ou, *ku, *kup, *kut, *on, *kn, *dou, *dku, *ds;
   float4* partial;
   size_t total;
 };
@@ -79,6 +79,7 @@ static SlWs sl_carve(int Bq, int Bk, char* base) {
   };
   w.ou = (float*)take((size_t)Bq * 1024);
   w.ku = (float*)take((size_t)Bk * 1024);
+  w.kup = (float*)take(rp_packed_floats(Bk, 256) * 4);
   w.kut = (float*)take((size_t)Bk * 1024);
   w.on = (float*)take((size_t)Bq * 4);
   w.kn = (float*)take((size_t)Bk * 4);
@@ -118,9 +119,11 @@ extern "C" int st_simloss_fwd(const float* ori, const float* like, int Bq, int B
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, (float*)nullptr);
   ST_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((rp_packed_floats(Bk, 256) / 4 + 255) / 256)), dim3(256), 0, st, w.ku, Bk, 256, w.kup);
+  ST_LAUNCH_CHECK();
   GemmArgs g = {};
-  g.X = w.ou; g.n_host = Bq; g.W = w.ku; g.N = Bk; g.scale = 1.0f / tau; g.row_offset = row_offset; g.partial = w.partial;
-  ST_TRY(launch_panel<EPI_LSE>(g, Bq, SL_SPLITS, st));
+  g.X = w.ou; g.n_host = Bq; g.W = w.kup; g.N = Bk; g.scale = 1.0f / tau; g.row_offset = row_offset; g.partial = w.partial;
+  ST_TRY(launch_rp<EPI_LSE>(g, Bq, SL_SPLITS, st));
   hipLaunchKernelGGL(lse_merge_kernel, dim3((Bq + 255) / 256), dim3(256), 0, st, w.partial, SL_SPLITS, Bq, loss, lse);
   ST_LAUNCH_CHECK();
   return ST_OK;
@@ -137,14 +140,16 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, w.kut);
   ST_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((rp_packed_floats(Bk, 256) / 4 + 255) / 256)), dim3(256), 0, st, w.ku, Bk, 256, w.kup);
+  ST_LAUNCH_CHECK();
   ST_HIP(hipMemsetAsync(w.dku, 0, (size_t)Bk * 1024, st));
   for (int r0 = 0; r0 < Bq; r0 += SL_CHUNK) {
     const int rows = (Bq - r0 < SL_CHUNK) ? Bq - r0 : SL_CHUNK;
     // dS chunk [rows, Bk]
     GemmArgs a = {};
-    a.X = w.ou + (size_t)r0 * 256; a.n_host = rows; a.W = w.ku; a.N = Bk; a.scale = 1.0f / tau;
+    a.X = w.ou + (size_t)r0 * 256; a.n_host = rows; a.W = w.kup; a.N = Bk; a.scale = 1.0f / tau;
     a.row_offset = row_offset + r0; a.lse = lse + r0; a.g = g + r0; a.out = w.ds; a.ldo = Bk;
-    ST_TRY(launch_panel<EPI_DS>(a, rows, (Bk + 1023) / 1024, st));
+    ST_TRY(launch_rp<EPI_DS>(a, rows, (Bk + 1023) / 1024, st));
     // d_ou[chunk] = dS . ku   (W = ku^T [256, Bk])
     GemmArgs b = {};
     b.X = w.ds; b.n_host = rows; b.K = Bk; b.W = w.kut; b.N = 256; b.out = w.dou + (size_t)r0 * 256; b.ldo = 256;

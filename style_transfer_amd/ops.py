@@ -113,10 +113,21 @@ def scorer_edit_step(sw, latent, adam_m, adam_v, like_z, unlike_z, lr, step, act
     return loss, grad
 
 
-def gemm_argmax(h, W, b, ln_a=None, ln_b=None):
-    _f32(h); _f32(W); _f32(b)
-    n, V = h.shape[0], W.shape[0]
-    assert h.shape[1] == 256 and W.shape[1] == 256
+def pack_weight(W):
+    """nn.Linear weight [N,K] (device f32) -> MFMA-fragment-ordered image (st_pack_weight)."""
+    _f32(W)
+    N, K = W.shape
+    out = torch.empty(lib().st_packed_weight_floats(N, K), dtype=torch.float32, device=W.device)
+    check(lib().st_pack_weight(W.data_ptr(), N, K, out.data_ptr(), _stream()), "st_pack_weight")
+    return out
+
+
+def gemm_argmax(h, W, b, ln_a=None, ln_b=None, packed=None):
+    """W [V,256] plain (packed here) or pass packed=pack_weight(W)."""
+    _f32(h); _f32(b)
+    n, V = h.shape[0], b.shape[0]
+    assert h.shape[1] == 256
+    W = packed if packed is not None else pack_weight(W)
     ids = torch.empty(n, dtype=torch.int32, device=h.device)
     best = torch.empty(n, dtype=torch.float32, device=h.device)
     gap = torch.empty(n, dtype=torch.float32, device=h.device)

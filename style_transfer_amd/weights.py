@@ -53,6 +53,13 @@ class _Packed:
         self._keep.append(d)
         return d.data_ptr()
 
+    def packed(self, t: torch.Tensor) -> int:
+        """[N,K] Linear weight -> fragment-ordered device image (st_pack_weight)."""
+        from . import ops
+        d = ops.pack_weight(t.detach().to(dtype=torch.float32).contiguous().to(self.device))
+        self._keep.append(d)
+        return d.data_ptr()
+
 
 class AEWeights(_Packed):
     """Decoder + encoder weights of the Transformer autoencoder (model.py:302-324)."""
@@ -75,19 +82,19 @@ class AEWeights(_Packed):
             s.d_model, s.n_heads, s.d_ff, s.n_layers, s.vocab, s.pe_rows = self.d_model, 4, self.d_ff, self.n_layers, self.vocab, pe.shape[0]
         self.dec.emb, self.dec.pe = self.emb_ptr, self.pe_ptr
         self.dec.lnf_a, self.dec.lnf_b = self.dev(sd["decoder.norm.a_2"]), self.dev(sd["decoder.norm.b_2"])
-        self.dec.gen_w, self.dec.gen_b = self.dev(sd["generator.proj.weight"]), self.dev(sd["generator.proj.bias"])
+        self.dec.gen_w, self.dec.gen_b = self.packed(sd["generator.proj.weight"]), self.dev(sd["generator.proj.bias"])
         for l in range(self.n_layers):
             p = "decoder.layers.%d." % l
             y = self.dec.layer[l]
             y.ln0_a, y.ln0_b = self.dev(sd[p + "sublayer.0.norm.a_2"]), self.dev(sd[p + "sublayer.0.norm.b_2"])
-            y.wqkv = self.dev(torch.cat([sd[p + "self_attn.linears.%d.weight" % i] for i in range(3)], 0))
+            y.wqkv = self.packed(torch.cat([sd[p + "self_attn.linears.%d.weight" % i] for i in range(3)], 0))
             y.bqkv = self.dev(torch.cat([sd[p + "self_attn.linears.%d.bias" % i] for i in range(3)], 0))
-            y.wo, y.bo = self.dev(sd[p + "self_attn.linears.3.weight"]), self.dev(sd[p + "self_attn.linears.3.bias"])
-            y.xv_w, y.xv_b = self.dev(sd[p + "src_attn.linears.2.weight"]), self.dev(sd[p + "src_attn.linears.2.bias"])
-            y.xo_w, y.xo_b = self.dev(sd[p + "src_attn.linears.3.weight"]), self.dev(sd[p + "src_attn.linears.3.bias"])
+            y.wo, y.bo = self.packed(sd[p + "self_attn.linears.3.weight"]), self.dev(sd[p + "self_attn.linears.3.bias"])
+            y.xv_w, y.xv_b = self.packed(sd[p + "src_attn.linears.2.weight"]), self.dev(sd[p + "src_attn.linears.2.bias"])
+            y.xo_w, y.xo_b = self.packed(sd[p + "src_attn.linears.3.weight"]), self.dev(sd[p + "src_attn.linears.3.bias"])
             y.ln2_a, y.ln2_b = self.dev(sd[p + "sublayer.2.norm.a_2"]), self.dev(sd[p + "sublayer.2.norm.b_2"])
-            y.w1, y.b1 = self.dev(sd[p + "feed_forward.w_1.weight"]), self.dev(sd[p + "feed_forward.w_1.bias"])
-            y.w2, y.b2 = self.dev(sd[p + "feed_forward.w_2.weight"]), self.dev(sd[p + "feed_forward.w_2.bias"])
+            y.w1, y.b1 = self.packed(sd[p + "feed_forward.w_1.weight"]), self.dev(sd[p + "feed_forward.w_1.bias"])
+            y.w2, y.b2 = self.packed(sd[p + "feed_forward.w_2.weight"]), self.dev(sd[p + "feed_forward.w_2.bias"])
         self.enc = _lib.StEncoderWeights()
         s = self.enc
         n_enc = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
@@ -98,12 +105,12 @@ class AEWeights(_Packed):
             p = "encoder.layers.%d." % l
             y = s.layer[l]
             y.ln0_a, y.ln0_b = self.dev(sd[p + "sublayer.0.norm.a_2"]), self.dev(sd[p + "sublayer.0.norm.b_2"])
-            y.wqkv = self.dev(torch.cat([sd[p + "self_attn.linears.%d.weight" % i] for i in range(3)], 0))
+            y.wqkv = self.packed(torch.cat([sd[p + "self_attn.linears.%d.weight" % i] for i in range(3)], 0))
             y.bqkv = self.dev(torch.cat([sd[p + "self_attn.linears.%d.bias" % i] for i in range(3)], 0))
-            y.wo, y.bo = self.dev(sd[p + "self_attn.linears.3.weight"]), self.dev(sd[p + "self_attn.linears.3.bias"])
+            y.wo, y.bo = self.packed(sd[p + "self_attn.linears.3.weight"]), self.dev(sd[p + "self_attn.linears.3.bias"])
             y.ln1_a, y.ln1_b = self.dev(sd[p + "sublayer.1.norm.a_2"]), self.dev(sd[p + "sublayer.1.norm.b_2"])
-            y.w1, y.b1 = self.dev(sd[p + "feed_forward.w_1.weight"]), self.dev(sd[p + "feed_forward.w_1.bias"])
-            y.w2, y.b2 = self.dev(sd[p + "feed_forward.w_2.weight"]), self.dev(sd[p + "feed_forward.w_2.bias"])
+            y.w1, y.b1 = self.packed(sd[p + "feed_forward.w_1.weight"]), self.dev(sd[p + "feed_forward.w_1.bias"])
+            y.w2, y.b2 = self.packed(sd[p + "feed_forward.w_2.weight"]), self.dev(sd[p + "feed_forward.w_2.bias"])
 
 
 def fold_bn(w, b, bn_w, bn_b, mean, var, eps=1e-5):

@@ -20,15 +20,20 @@ def timeit(fn, iters=10, warm=3):
     return a.elapsed_time(b) / iters * 1e-3
 
 
-def argmax_bench(V=9339):
+def argmax_bench(V=9339, sizes=(64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536)):
     W = torch.randn(V, 256, device=dev) * 0.1
     b = torch.randn(V, device=dev)
     la, lb = torch.randn(256, device=dev), torch.randn(256, device=dev)
-    for n in (64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+    for n in sizes:
         h = torch.randn(n, 256, device=dev)
-        t = timeit(lambda: ops.gemm_argmax(h, W, b, la, lb))
+        Wp = ops.pack_weight(W)
+        t = timeit(lambda: ops.gemm_argmax(h, None, b, la, lb, packed=Wp))
         print("gemm_argmax n=%6d V=%d: %8.1f us  %6.1f TFLOP/s" % (n, V, t * 1e6, 2.0 * n * 256 * V / t / 1e12), flush=True)
 
 
 if __name__ == "__main__":
-    argmax_bench(int(sys.argv[1]) if len(sys.argv) > 1 else 9339)
+    V = int(sys.argv[1]) if len(sys.argv) > 1 else 9339
+    if len(sys.argv) > 2:
+        argmax_bench(V, tuple(int(x) for x in sys.argv[2:]))
+    else:
+        argmax_bench(V)
