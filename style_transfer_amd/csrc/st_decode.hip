@@ -193,7 +193,7 @@ struct DecodeWs {
   int* cnt;        // [2]
   size_t total;
 };
-#define ST_GEN_SPLITS 4
+#define ST_GEN_SPLITS 16  /* max column splits of the generator (partials per row) */
 
 static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base) {
   DecodeWs ws;
@@ -293,18 +293,18 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
-      ST_TRY(launch_rp<EPI_QKV>(g, n_bound, 3, st));
+      ST_TRY(launch_rp<EPI_QKV>(g, n_bound, rp_splits(n_bound, 768, 6), st));
       hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
                          ws.att);
       ST_LAUNCH_CHECK();
       GemmArgs o = {};
       o.X = ws.att; o.n_dev = n_dev; o.n_host = n_bound; o.W = y.wo; o.bias = y.bo; o.N = 256;
       o.out = ws.x; o.ldo = 256; o.resid = ws.x; o.cconst = ws.cc + (size_t)l * B * 256; o.ld_cc = 256; o.idx = idx;
-      ST_TRY(launch_rp<EPI_RESID>(o, n_bound, 1, st));
+      ST_TRY(launch_rp<EPI_RESID>(o, n_bound, rp_splits(n_bound, 256, 2), st));
       GemmArgs f1 = {};
       f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
       f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
-      ST_TRY(launch_rp<EPI_RELU>(f1, n_bound, (w->d_ff + 255) / 256, st));
+      ST_TRY(launch_rp<EPI_RELU>(f1, n_bound, rp_splits(n_bound, w->d_ff, 8), st));
       GemmArgs f2 = {};
       f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
       f2.out = ws.x; f2.ldo = 256; f2.resid = ws.x;
@@ -315,9 +315,10 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
     ProfPair pp;
     if (g_prof_on) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
-    ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, ST_GEN_SPLITS, st));
+    const int gsplits = rp_splits(n_bound, w->vocab, ST_GEN_SPLITS) < 4 ? 4 : rp_splits(n_bound, w->vocab, ST_GEN_SPLITS);
+    ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, gsplits, st));
     if (g_prof_on) ST_TRY(prof_end(&pp, st));
-    hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, ST_GEN_SPLITS, idx,
+    hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx,
                        n_dev, out_ids, top2gap, T, pos, eos, pad, early, pos == T - 1 ? 1 : 0, ws.idx[cur ^ 1],
                        ws.cnt + (cur ^ 1));
     ST_LAUNCH_CHECK();

@@ -83,7 +83,20 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
   }
   const float* Ab = As + l31 * ST_LDA + 4 * half;
   f32x16 acc0 = {0}, acc1 = {0};
+  float pre[2][16];  // RESID: residual (+ cross-attention constant), fetched while the block's MFMAs run
   for (int g0 = 0; g0 < total; g0 += 8) {
+    if (EPI == EPI_RESID && (g0 & 31) == 0) {
+      const int col = min(((b0 + wave + 4 * (g0 >> 5)) << 5) + l31, a.N - 1);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(m0 + mi * 32 + mfma32_row(r, lane), n - 1);
+          float v = a.resid[(size_t)row * a.ldo + col];
+          if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
+          pre[mi][r] = v;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int kg = (g0 + j) & 31;
@@ -131,9 +144,7 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
             } else if (EPI == EPI_RELU) {
               a.out[(size_t)row * a.ldo + col] = fmaxf(v, 0.0f);
             } else if (EPI == EPI_RESID) {
-              v += a.resid[(size_t)row * a.ldo + col];
-              if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
-              a.out[(size_t)row * a.ldo + col] = v;
+              a.out[(size_t)row * a.ldo + col] = v + pre[mi][r];
             } else if (EPI == EPI_DS) {
               const float sv = v * a.scale;
               const float pr = expf(sv - a.lse[row]) - (col == a.row_offset + row ? 1.0f : 0.0f);
@@ -218,6 +229,18 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
   }
 }
 
+// number of column splits: enough workgroups for ~2 rounds on 256 CUs x 2, never fewer than one
+// 32-column block per wave, at most max_splits
+static inline int rp_splits(int n_rows, int N, int max_splits) {
+  const int panels = (n_rows + 63) / 64;
+  const int nblk = (N + 31) / 32;
+  int s = (1024 + panels - 1) / (panels > 0 ? panels : 1);
+  const int cap = (nblk + 3) / 4;
+  if (s > cap) s = cap;
+  if (s > max_splits) s = max_splits;
+  return s < 1 ? 1 : s;
+}
+
 template <int EPI>
 static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   static bool attr_done = false;
@@ -256,11 +279,25 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
     r0[j] = *(const f32x4*)(W0 + (size_t)min(j, total - 1) * 256);
     r1[j] = *(const f32x4*)(W1 + (size_t)min(j, total - 1) * 256);
   }
+  // accumulators start from bias (+ residual + cross constant): the fetch overlaps the whole K loop
   f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int nb = 0; nb < 2; ++nb) {
+    const int col = (wave + 4 * nb) * 32 + l31;
+    const float bv = a.bias ? a.bias[col] : 0.0f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = bv;
+        if (EPI == EPI_RESID) {
+          const int row = min(m0 + mi * 32 + mfma32_row(r, lane), n - 1);
+          v += a.resid[(size_t)row * a.ldo + col];
+          if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
+        }
+        acc[mi][nb][r] = v;
+      }
+  }
   const float* Ab = As + l31 * ST_LDA + 4 * half;
   for (int c = 0; c < nchunk; ++c) {
     if (c) __syncthreads();
@@ -294,19 +331,12 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int col = (wave + 4 * nb) * 32 + l31;
-    const float bv = a.bias ? a.bias[col] : 0.0f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + mi * 32 + mfma32_row(r, lane);
-        if (row >= n) continue;
-        float v = acc[mi][nb][r] + bv;
-        if (EPI == EPI_RESID) {
-          v += a.resid[(size_t)row * a.ldo + col];
-          if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
-        }
-        a.out[(size_t)row * a.ldo + col] = v;
+        if (row < n) a.out[(size_t)row * a.ldo + col] = acc[mi][nb][r];
       }
   }
 }
