@@ -35,7 +35,7 @@ def cpu_baseline(seconds_budget=20.0):
     ae = {k: v.numpy() for k, v in W.expand_ae_state_dict(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors"))).items()}
     ssd = {k: v.numpy() for k, v in W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")).items()}
     psd = {k: v.numpy() for k, v in W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")).items()}
-    data = AttackSet.synthetic(64, 9339, "yelp", seed=1234)
+    data = AttackSet.synthetic(2048, 9339, "yelp", seed=1234)
     id_to_word = [str(i) for i in range(9339)]
     t0 = time.perf_counter()
     done = 0
@@ -63,11 +63,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8192, help="sentences per GPU per step")
+    ap.add_argument("--batch", type=int, default=16384, help="sentences per GPU per step")
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
     ap.add_argument("--fixed-steps", action="store_true", help="no early exit at EOS: always 59 decode steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--iters-per-decode", type=int, default=6)
+    ap.add_argument("--iters-per-decode", type=int, default=9)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -143,7 +143,7 @@ def main():
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
                        "iters_per_decode": cfg.iters_per_decode,
                        "edit_iteration_units_per_s": world * units / dt},
-            "roofline": {"bound": "mfma", "kernel": "panel_gemm_kernel<EPI_ARGMAX> (generator GEMM + argmax)",
+            "roofline": {"bound": "mfma", "kernel": "rp_gemm_kernel<4> = EPI_ARGMAX (generator GEMM + fused argmax)",
                          "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": int(gen_n.value), "avg_launch_us": gen_ms.value * 1e3 / max(1, gen_n.value),

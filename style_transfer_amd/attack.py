@@ -50,7 +50,7 @@ class AttackConfig:
     log_decodes: bool = True       # the 1+10+10 decodes behind the Rec:/Sim:/Ref: log lines
     want_gap: bool = False
     want_trace: bool = False       # keep latents / grads / losses per iteration (parity tests)
-    iters_per_decode: int = 6      # edit iterations whose latents are decoded together as one batch
+    iters_per_decode: int = 9      # edit iterations whose latents are decoded together as one batch
     count_units: bool = False
 
     @classmethod

@@ -197,6 +197,9 @@ def main(argv=None):
         raise ValueError("checkpoint vocabulary %d != word_to_id vocabulary %d" % (ae.vocab, vocab_size))
     # load_siamese (siamese_contrastive.py:1565-1587): exit(0) when a file is missing
     sp, pp = os.path.join(save_path, 'siamese_model_params.pkl'), os.path.join(save_path, 'predictor_net_params.pkl')
+    # the same state-dicts re-saved as safetensors (tests/golden) are accepted when the .pkl is absent
+    alt = lambda q: q if os.path.exists(q) or not os.path.exists(q[:-4] + '.safetensors') else q[:-4] + '.safetensors'
+    sp, pp = alt(sp), alt(pp)
     if rank == 0:
         print('Loading Siamese Net from {}'.format(save_path))
     if not os.path.exists(sp):

@@ -129,3 +129,27 @@ def test_log_is_byte_identical_to_reference(env, gold_notnll, tmp_path):
     a = extract_out(mine, 2, 2, limit=S)
     b = extract_out(ref, 2, 2, limit=S)
     assert sum(1 for x, y in zip(a, b) if x == y) >= S - 1
+
+
+def test_cli_full_yelp_test_set_batch256(env, gold_notnll, tmp_path, capsys):
+    """BASELINE config 2: the whole 1000-sentence yelp test split through the CLI at batch 256; the 64
+    sentences that have reference goldens must come out identical, and every sentence must have an
+    `iteration.0` record (get_i_iter.py:137-138)."""
+    from style_transfer_amd import main as M
+    from style_transfer_amd.logfmt import extract_out
+    log = tmp_path / "yelp_log"
+    rc = M.main(["--attack", "--not_nll", "--pos_victim_lr=0.2", "--neg_victim_lr=0.2", "--save_path", GOLD + "/",
+                 "--data_path", os.path.join(GOLD, "yelp") + "/", "--ae_checkpoint", "surrogate_ae_yelp.safetensors",
+                 "--attack_batch", "256", "--quiet", "--log_file", str(log)])
+    assert rc == 0
+    lines = open(log).read().splitlines()
+    out = extract_out(lines, 2, 2)
+    assert len(out) == 1000 and all(o.endswith("\n") for o in out)
+    blocks = "\n".join(lines).split("Sentence Pair.")[1:]
+    assert len(blocks) == 1000
+    ref = open(os.path.join(GOLD, "attack_notnll_log.txt")).read().split("Sentence Pair.")[1:]
+    body = lambda b: b.split("\n", 1)[1].rsplit("\n", 1)[0]   # drop the index on the first line and the next headline
+    same = 0
+    for k, s in enumerate(gold_notnll["subset"]):
+        same += int(body(blocks[int(s)]) == body(ref[k]))
+    assert same == len(ref), same
