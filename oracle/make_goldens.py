@@ -221,6 +221,8 @@ if __name__ == "__main__":
         sub = [0, 1, 2, 500, 501, 502]
         if not os.path.exists(os.path.join(GOLD, "attack_nll.npz")):
             run_attack(sub, dict(), ckpt, "nll", a.threads)
-        run_attack(sub, dict(just_use_one=True), ckpt, "nll_one", a.threads)
-        run_attack(sub, dict(not_nll=True, simplest_siamese=True, pos_victim_lr=0.2, neg_victim_lr=0.3), ckpt, "simplest", a.threads)
+        if not os.path.exists(os.path.join(GOLD, "attack_nll_one.npz")):
+            run_attack(sub, dict(just_use_one=True), ckpt, "nll_one", a.threads)
+        if not os.path.exists(os.path.join(GOLD, "attack_simplest.npz")):
+            run_attack(sub, dict(not_nll=True, simplest_siamese=True, pos_victim_lr=0.2, neg_victim_lr=0.3), ckpt, "simplest", a.threads)
         run_attack(sub, dict(not_nll=True, pos_num=3, neg_num=5, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "p3n5", a.threads)

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libst_kernels.so")
+LIB_PATH = os.environ.get("ST_KERNELS_LIB") or os.path.join(HERE, "libst_kernels.so")  # override: A/B kernel builds
 
 ST_MAX_LAYERS = 4
 ST_MAX_REFS = 16

@@ -297,14 +297,22 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
                          ws.att);
       ST_LAUNCH_CHECK();
-      GemmArgs o = {};
-      o.X = ws.att; o.n_dev = n_dev; o.n_host = n_bound; o.W = y.wo; o.bias = y.bo; o.N = 256;
-      o.out = ws.x; o.ldo = 256; o.resid = ws.x; o.cconst = ws.cc + (size_t)l * B * 256; o.ld_cc = 256; o.idx = idx;
-      ST_TRY(launch_rp<EPI_RESID>(o, n_bound, rp_splits(n_bound, 256, 2), st));
-      GemmArgs f1 = {};
-      f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
-      f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
-      ST_TRY(launch_rp<EPI_RELU>(f1, n_bound, rp_splits(n_bound, w->d_ff, 8), st));
+      if (n_bound >= RP_FUSE_MIN_ROWS) {
+        OFArgs of = {};
+        of.att = ws.att; of.n_dev = n_dev; of.n_host = n_bound; of.wo = y.wo; of.bo = y.bo; of.x = ws.x;
+        of.cconst = ws.cc + (size_t)l * B * 256; of.idx = idx; of.ln_a = y.ln2_a; of.ln_b = y.ln2_b;
+        of.w1 = y.w1; of.b1 = y.b1; of.h = ws.h; of.d_ff = w->d_ff;
+        ST_TRY(launch_oproj_ffn1(of, n_bound, st));
+      } else {
+        GemmArgs o = {};
+        o.X = ws.att; o.n_dev = n_dev; o.n_host = n_bound; o.W = y.wo; o.bias = y.bo; o.N = 256;
+        o.out = ws.x; o.ldo = 256; o.resid = ws.x; o.cconst = ws.cc + (size_t)l * B * 256; o.ld_cc = 256; o.idx = idx;
+        ST_TRY(launch_rp<EPI_RESID>(o, n_bound, rp_splits(n_bound, 256, 2), st));
+        GemmArgs f1 = {};
+        f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
+        f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
+        ST_TRY(launch_rp<EPI_RELU>(f1, n_bound, rp_splits(n_bound, w->d_ff, 8), st));
+      }
       GemmArgs f2 = {};
       f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
       f2.out = ws.x; f2.ldo = 256; f2.resid = ws.x;

@@ -125,13 +125,20 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     ST_TRY(launch_rp<EPI_BIAS>(g, R, rp_splits(R, 768, 6), st));
     hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
     ST_LAUNCH_CHECK();
-    GemmArgs o = {};
-    o.X = att; o.n_host = R; o.W = y.wo; o.bias = y.bo; o.N = 256; o.out = x; o.ldo = 256; o.resid = x;
-    ST_TRY(launch_rp<EPI_RESID>(o, R, rp_splits(R, 256, 2), st));
-    GemmArgs f1 = {};
-    f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
-    f1.out = h; f1.ldo = w->d_ff;
-    ST_TRY(launch_rp<EPI_RELU>(f1, R, rp_splits(R, w->d_ff, 8), st));
+    if (R >= RP_FUSE_MIN_ROWS) {
+      OFArgs of = {};
+      of.att = att; of.n_host = R; of.wo = y.wo; of.bo = y.bo; of.x = x; of.ln_a = y.ln1_a; of.ln_b = y.ln1_b;
+      of.w1 = y.w1; of.b1 = y.b1; of.h = h; of.d_ff = w->d_ff;
+      ST_TRY(launch_oproj_ffn1(of, R, st));
+    } else {
+      GemmArgs o = {};
+      o.X = att; o.n_host = R; o.W = y.wo; o.bias = y.bo; o.N = 256; o.out = x; o.ldo = 256; o.resid = x;
+      ST_TRY(launch_rp<EPI_RESID>(o, R, rp_splits(R, 256, 2), st));
+      GemmArgs f1 = {};
+      f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
+      f1.out = h; f1.ldo = w->d_ff;
+      ST_TRY(launch_rp<EPI_RELU>(f1, R, rp_splits(R, w->d_ff, 8), st));
+    }
     GemmArgs f2 = {};
     f2.X = h; f2.n_host = R; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256; f2.out = x; f2.ldo = 256; f2.resid = x;
     ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, R, st));

@@ -358,6 +358,174 @@ static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused post-attention half-layer:  x1 = att.Wo^T + bo + x (+ cross-attention constant);  x <- x1;
+// h = relu(LayerNorm(x1).W1^T + b1).   One 64-row panel: the attention output is the LDS panel for the
+// O-projection (wave w owns column blocks w, w+4), x1 replaces it in LDS, is normalised in place and
+// becomes the panel for feed_forward.w_1 (N = d_ff, blocks w, w+4, ...).  Saves a launch, one panel
+// load and the x round trip of the unfused pair rp_gemm<RESID> + rp_gemm<RELU>.
+// ------------------------------------------------------------------------------------------------
+struct OFArgs {
+  const float* att;    // [n,256]
+  const int* n_dev;
+  int n_host;
+  const float *wo, *bo;          // packed [256,256], [256]
+  float* x;                      // [n,256] residual in, x1 out
+  const float* cconst;           // optional [S,256]
+  const int* idx;
+  const float *ln_a, *ln_b;      // LayerNorm before the FFN
+  const float *w1, *b1;          // packed [d_ff,256], [d_ff]
+  float* h;                      // [n,d_ff]
+  int d_ff;
+};
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int f = tid + i * 256;
+    const int r = f >> 6, c4 = f & 63;
+    *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+  }
+  // ---- phase 1: O-projection, accumulators start from bias + residual (+ constant) ----
+  const float* W0 = a.wo + ((size_t)wave * 32) * 256 + (size_t)lane * 4;
+  const float* W1 = a.wo + ((size_t)(wave + 4) * 32) * 256 + (size_t)lane * 4;
+  f32x4 r0[4], r1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r0[j] = *(const f32x4*)(W0 + (size_t)j * 256);
+    r1[j] = *(const f32x4*)(W1 + (size_t)j * 256);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int col = (wave + 4 * nb) * 32 + l31;
+    const float bv = a.bo[col];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(m0 + mi * 32 + mfma32_row(r, lane), n - 1);
+        float v = bv + a.x[(size_t)row * 256 + col];
+        if (a.cconst) v += a.cconst[(size_t)a.idx[row] * 256 + col];
+        acc[mi][nb][r] = v;
+      }
+  }
+  __syncthreads();
+  const float* Ab = As + l31 * ST_LDA + 4 * half;
+  for (int g0 = 0; g0 < 32; g0 += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kg = g0 + j;
+      const f32x4 b0 = r0[j], b1 = r1[j];
+      const int nx = min(kg + 4, 31);
+      r0[j] = *(const f32x4*)(W0 + (size_t)nx * 256);
+      r1[j] = *(const f32x4*)(W1 + (size_t)nx * 256);
+      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+      const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
+        acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
+        acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
+        acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+      }
+    }
+  }
+  __syncthreads();  // every wave is done reading the attention panel
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int col = (wave + 4 * nb) * 32 + l31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = mi * 32 + mfma32_row(r, lane);
+        const float v = acc[mi][nb][r];
+        As[lr * ST_LDA + col] = v;
+        if (m0 + lr < n) a.x[(size_t)(m0 + lr) * 256 + col] = v;
+      }
+  }
+  __syncthreads();
+  {
+    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      float* p = As + (wave * 16 + rr) * ST_LDA + lane * 4;
+      *(f32x4*)p = layernorm256(*(f32x4*)p, ga, gb);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: h = relu(xn . W1^T + b1), this wave's blocks wave, wave+4, ... ----
+  const int nblk = a.d_ff >> 5;
+  const int cnt = (nblk - wave + 3) >> 2;
+  const int total = cnt * 32;
+  const float* Wl = a.w1 + (size_t)lane * 4;
+  auto wload = [&](int g) -> f32x4 {
+    g = min(g, total - 1);
+    return *(const f32x4*)(Wl + ((size_t)(wave + 4 * (g >> 5)) * 32 + (g & 31)) * 256);
+  };
+  f32x4 ring[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ring[j] = wload(j);
+  f32x16 acc0 = {0}, acc1 = {0};
+  for (int g0 = 0; g0 < total; g0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kg = (g0 + j) & 31;
+      const f32x4 b = ring[j];
+      ring[j] = wload(g0 + j + 8);
+      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+      const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc0 = mfma32(a0[s], b[s], acc0);
+        acc1 = mfma32(a1[s], b[s], acc1);
+      }
+    }
+    if (((g0 + 8) & 31) == 0) {
+      const int col = ((wave + 4 * (g0 >> 5)) << 5) + l31;
+      const float bv = a.b1[col];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x16 ac = mi ? acc1 : acc0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + mi * 32 + mfma32_row(r, lane);
+#ifdef ST_ABLATE_HSTORE
+          if (row < n && ac[r] == 12345.678f) a.h[(size_t)row * a.d_ff + col] = fmaxf(ac[r] + bv, 0.0f);
+#else
+          if (row < n) a.h[(size_t)row * a.d_ff + col] = fmaxf(ac[r] + bv, 0.0f);
+#endif
+        }
+      }
+      acc0 = (f32x16){0};
+      acc1 = (f32x16){0};
+    }
+  }
+}
+
+#define RP_FUSE_MIN_ROWS 16384  /* below this the unfused pair (with column splits) fills the chip better */
+static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)rp_oproj_ffn1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  hipLaunchKernelGGL(rp_oproj_ffn1_kernel<0>, dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
 // packed-weight helpers -------------------------------------------------------------------------
 static inline size_t rp_packed_floats(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }
 

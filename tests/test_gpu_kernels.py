@@ -278,3 +278,26 @@ def test_errors_are_reported_not_thrown_across_abi(dev, ae):
     from style_transfer_amd import ops, _lib
     with pytest.raises(_lib.StError, match="max_len"):
         ops.greedy_decode(ae, torch.zeros(2, 256, device=dev), max_len=100)
+
+
+def test_large_batch_paths_equal_small_batch(dev, ae, ae_sd):
+    """Full-size property: above 16384 rows the decoder / encoder switch to the fused O-projection+FFN1
+    kernel and multi-round grids; every replica of a sentence must produce exactly the ids / (nearly) the
+    latent of the small-batch run that the oracle checks above."""
+    from style_transfer_amd import ops
+    from style_transfer_amd.data import pack_sentences
+    sents = some_sentences(40, seed=11)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    tok, pos, off, mx = pack_sentences(sents)
+    lat_small = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx)
+    reps = 60                                             # 2400 sentences, > 16384 token rows
+    tok, pos, off, mx = pack_sentences(sents * reps)
+    assert tok.size >= 16384
+    lat_big = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents) * reps, mx)
+    d = (lat_big.view(reps, len(sents), 256) - lat_small[None]).abs().max().item()
+    assert d < 1e-4 * lat_small.abs().max().item(), d
+    ids_small, _, _ = ops.greedy_decode(ae, lat_small)
+    big = lat_small.repeat(450, 1).contiguous()           # 18000 decode jobs
+    ids_big, _, _ = ops.greedy_decode(ae, big)
+    same = (ids_big.view(450, len(sents), 59) == ids_small[None]).all(dim=2).all(dim=0)
+    assert int(same.sum().item()) >= len(sents) - 1, same.cpu().tolist()

@@ -1,0 +1,129 @@
+// Stand-alone micro-benchmark of the row-panel GEMM kernels (random data, HIP events).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I style_transfer_amd/csrc tools/kbench.cpp -o build_variants/kbench [-D...]
+#include "st_rowpanel.h"
+
+#include <stdarg.h>
+#include <stdlib.h>
+#include <vector>
+
+void st_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "\n");
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+static float* dev_rand(size_t n, float scale, unsigned seed) {
+  std::vector<float> h(n);
+  unsigned s = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 1664525u + 1013904223u;
+    h[i] = ((s >> 8) / 16777216.0f * 2.0f - 1.0f) * scale;
+  }
+  float* d;
+  CK(hipMalloc(&d, n * 4));
+  CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+  return d;
+}
+static float* pack(const float* W, int N, int K) {
+  float* out;
+  CK(hipMalloc(&out, rp_packed_floats(N, K) * 4));
+  size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
+  hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, W, N, K, out);
+  CK(hipDeviceSynchronize());
+  return out;
+}
+template <class F>
+static double timeit(F f, int iters = 10) {
+  for (int i = 0; i < 3; ++i) f();
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < iters; ++i) f();
+  CK(hipEventRecord(b, 0));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms * 1e-3 / iters;
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 65536;
+  const int V = 9339, DFF = 1024;
+  float* x = dev_rand((size_t)n * 256, 1.0f, 1);
+  float* att = dev_rand((size_t)n * 256, 1.0f, 2);
+  float* h;
+  CK(hipMalloc(&h, (size_t)n * DFF * 4));
+  float* q;
+  CK(hipMalloc(&q, (size_t)n * 768 * 4));
+  float* ln_a = dev_rand(256, 1.0f, 3);
+  float* ln_b = dev_rand(256, 0.1f, 4);
+  float* wo = dev_rand(256 * 256, 0.06f, 5);
+  float* w1 = dev_rand((size_t)DFF * 256, 0.06f, 6);
+  float* w2 = dev_rand((size_t)256 * DFF, 0.03f, 7);
+  float* wqkv = dev_rand((size_t)768 * 256, 0.06f, 8);
+  float* wg = dev_rand((size_t)V * 256, 0.06f, 9);
+  float* bias = dev_rand(16384, 0.1f, 10);
+  float *wo_p = pack(wo, 256, 256), *w1_p = pack(w1, DFF, 256), *w2_p = pack(w2, 256, DFF), *wqkv_p = pack(wqkv, 768, 256),
+        *wg_p = pack(wg, V, 256);
+  float4* partial;
+  CK(hipMalloc(&partial, (size_t)n * 16 * 16));
+  hipStream_t st = 0;
+  double t;
+
+  {  // generator
+    GemmArgs g = {};
+    g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
+    const int sp = rp_splits(n, V, 16) < 4 ? 4 : rp_splits(n, V, 16);
+    t = timeit([&] { launch_rp<EPI_ARGMAX>(g, n, sp, st); });
+    printf("generator  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
+  }
+  {  // FFN1 (rp RELU)
+    GemmArgs g = {};
+    g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = w1_p; g.bias = bias; g.N = DFF; g.out = h; g.ldo = DFF;
+    const int sp = rp_splits(n, DFF, 8);
+    t = timeit([&] { launch_rp<EPI_RELU>(g, n, sp, st); });
+    printf("ffn1       n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * DFF / t / 1e12);
+  }
+  {  // QKV as plain BIAS store to [n,768]
+    GemmArgs g = {};
+    g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wqkv_p; g.bias = bias; g.N = 768; g.out = q; g.ldo = 768;
+    const int sp = rp_splits(n, 768, 6);
+    t = timeit([&] { launch_rp<EPI_BIAS>(g, n, sp, st); });
+    printf("qkv(bias)  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
+  }
+  {  // O-proj RESID
+    GemmArgs g = {};
+    g.X = att; g.n_host = n; g.W = wo_p; g.bias = bias; g.N = 256; g.out = x; g.ldo = 256; g.resid = x;
+    const int sp = rp_splits(n, 256, 2);
+    t = timeit([&] { launch_rp<EPI_RESID>(g, n, sp, st); });
+    printf("oproj      n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 256 / t / 1e12);
+  }
+  {  // FFN2 kchunk
+    GemmArgs g = {};
+    g.X = h; g.n_host = n; g.K = DFF; g.W = w2_p; g.bias = bias; g.N = 256; g.out = x; g.ldo = 256; g.resid = x;
+    t = timeit([&] { launch_rp_kchunk<EPI_RESID>(g, n, st); });
+    printf("ffn2       n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * DFF / t / 1e12);
+  }
+  {  // fused O + FFN1
+    OFArgs a = {};
+    a.att = att; a.n_host = n; a.wo = wo_p; a.bo = bias; a.x = x; a.ln_a = ln_a; a.ln_b = ln_b; a.w1 = w1_p; a.b1 = bias;
+    a.h = h; a.d_ff = DFF;
+    t = timeit([&] { launch_oproj_ffn1(a, n, st); });
+    printf("oproj+ffn1 n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + DFF) / t / 1e12);
+  }
+#ifdef HAVE_LAYER_FUSED
+  {
+    LayerArgs a = {};
+    a.att = att; a.n_host = n; a.wo = wo_p; a.bo = bias; a.x = x; a.ln_a = ln_a; a.ln_b = ln_b; a.w1 = w1_p; a.b1 = bias;
+    a.w2 = w2_p; a.b2 = bias; a.d_ff = DFF;
+    t = timeit([&] { launch_layer_fused(a, n, st); });
+    printf("layer      n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + 2 * DFF) / t / 1e12);
+  }
+#endif
+  CK(hipDeviceSynchronize());
+  return 0;
+}
