@@ -59,8 +59,8 @@ int st_pack_weight(const float* W, int N, int K, float* out_packed, void* stream
 
 /* SiameseNet (siamese_contrastive.py:29-63) and Predictor (:66-86) in eval mode.  BatchNorm1d
  * (eval, running stats) is folded into the preceding Linear by the host:  W' = s*W, b' = s*b + t
- * with s = gamma/sqrt(var+eps), t = beta - mean*s.   Each matrix is given row-major [out,in] (`w`)
- * AND transposed [in,out] (`wt`, used by the backward pass).  The Predictor hidden width (100) is
+ * with s = gamma/sqrt(var+eps), t = beta - mean*s.   Each matrix is given as [out,in] (`w`) AND as its
+ * transpose [in,out] (`wt`, used by the backward pass), both PACKED with st_pack_weight.  The Predictor hidden width (100) is
  * zero-padded to 128 by the host.                                                              */
 typedef struct StScorerWeights {
   const float *s1_w, *s1_wt, *s1_b;   /* 256 -> 512 (+BN1 folded), ReLU          */

@@ -225,4 +225,6 @@ if __name__ == "__main__":
             run_attack(sub, dict(just_use_one=True), ckpt, "nll_one", a.threads)
         if not os.path.exists(os.path.join(GOLD, "attack_simplest.npz")):
             run_attack(sub, dict(not_nll=True, simplest_siamese=True, pos_victim_lr=0.2, neg_victim_lr=0.3), ckpt, "simplest", a.threads)
-        run_attack(sub, dict(not_nll=True, pos_num=3, neg_num=5, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "p3n5", a.threads)
+        # (--not_nll with pos_num != neg_num raises in the reference: pos_loss [K+] + neg_loss [K-], :429)
+        run_attack(sub, dict(pos_num=3, neg_num=5), ckpt, "p3n5", a.threads)
+        run_attack(sub, dict(not_nll=True, pos_num=4, neg_num=4, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "p4n4", a.threads)

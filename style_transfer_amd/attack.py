@@ -128,6 +128,9 @@ class AttackRunner:
         B, kp, kn = prep["B"], prep["kp"], prep["kn"]
         T = c.max_sequence_length - 1
         I = 2 if c.dance else c.attack_max_iter
+        if c.not_nll and kp != kn and kp and kn:
+            # the reference adds pos_loss [K+] to neg_loss [K-] (siamese_contrastive.py:429): a size-mismatch error
+            raise ValueError("--not_nll needs pos_num == neg_num (got %d and %d), as in the reference" % (kp, kn))
         tm = {}
         t0 = time.perf_counter()
         lat_all = self.encode_prepared(prep)

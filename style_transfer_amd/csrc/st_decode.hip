@@ -122,9 +122,18 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
   const float m = wave_max(sc);
   const float e = lane <= pos ? expf(sc - m) : 0.0f;
   const float p = e / wave_sum(e);
-  float o = 0.0f;
-  for (int j = 0; j <= pos; ++j) o = fmaf(__shfl(p, j, 64), V[(size_t)j * 256 + lane], o);
-  out[(size_t)r * 256 + h * 64 + lane] = o;
+  float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;   // four independent chains keep four V loads in flight
+  int j = 0;
+  for (; j + 3 <= pos; j += 4) {
+    const float v0 = V[(size_t)j * 256 + lane], v1 = V[(size_t)(j + 1) * 256 + lane];
+    const float v2 = V[(size_t)(j + 2) * 256 + lane], v3 = V[(size_t)(j + 3) * 256 + lane];
+    o0 = fmaf(__shfl(p, j, 64), v0, o0);
+    o1 = fmaf(__shfl(p, j + 1, 64), v1, o1);
+    o2 = fmaf(__shfl(p, j + 2, 64), v2, o2);
+    o3 = fmaf(__shfl(p, j + 3, 64), v3, o3);
+  }
+  for (; j <= pos; ++j) o0 = fmaf(__shfl(p, j, 64), V[(size_t)j * 256 + lane], o0);
+  out[(size_t)r * 256 + h * 64 + lane] = (o0 + o1) + (o2 + o3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -323,7 +332,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
     ProfPair pp;
     if (g_prof_on) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
-    const int gsplits = rp_splits(n_bound, w->vocab, ST_GEN_SPLITS) < 4 ? 4 : rp_splits(n_bound, w->vocab, ST_GEN_SPLITS);
+    const int gsplits = rp_splits(n_bound, w->vocab, ST_GEN_SPLITS);
     ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, gsplits, st));
     if (g_prof_on) ST_TRY(prof_end(&pp, st));
     hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx,

@@ -229,16 +229,29 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
   }
 }
 
-// number of column splits: enough workgroups for ~2 rounds on 256 CUs x 2, never fewer than one
-// 32-column block per wave, at most max_splits
+// number of column splits: enough workgroups for ~2 rounds on 256 CUs x 2 workgroups, at most max_splits,
+// never fewer than one 32-column block per wave; among the admissible counts prefer the one whose
+// per-wave block count is best balanced (a workgroup lasts as long as its busiest wave).
 static inline int rp_splits(int n_rows, int N, int max_splits) {
   const int panels = (n_rows + 63) / 64;
   const int nblk = (N + 31) / 32;
-  int s = (1024 + panels - 1) / (panels > 0 ? panels : 1);
+  int want = (1024 + panels - 1) / (panels > 0 ? panels : 1);
   const int cap = (nblk + 3) / 4;
-  if (s > cap) s = cap;
-  if (s > max_splits) s = max_splits;
-  return s < 1 ? 1 : s;
+  if (want > cap) want = cap;
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  int best = want;
+  double best_eff = 0.0;
+  for (int s = want; s <= max_splits && s <= cap && s <= want * 2; ++s) {
+    const int per = (nblk + s - 1) / s;          // blocks per workgroup
+    const int busiest = (per + 3) / 4;           // blocks of the busiest wave
+    const double eff = (double)nblk / ((double)s * 4.0 * busiest);
+    if (eff > best_eff + 0.02) {
+      best_eff = eff;
+      best = s;
+    }
+  }
+  return best;
 }
 
 template <int EPI>

@@ -6,7 +6,8 @@
 // Only d(loss)/d(latent) is needed, so the backward pass needs no stored activations — just the
 // ReLU / LeakyReLU sign masks (kept as ballot bit-words) and the transposed weights.
 // Products run on v_mfma_f32_32x32x2_f32 (exact f32): M = 32 sentences, A from LDS, B (weights)
-// straight from L2 in the lane layout of st_gemm.h (weights are 2.3 MB, read once per tile).
+// straight from L2, fragment-packed by st_pack_weight so each wave load is one coalesced 1 KiB read
+// (weights are 2.3 MB, read once per tile).
 #include "st_common.h"
 
 #define SC_LD 516        // activation row stride in floats (512 + 4; = 4 mod 64 -> conflict-free b128)
@@ -28,11 +29,11 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float*
   for (int c = wave; c < N / 32; c += 4) {
     f32x16 acc = {0};
     const float* xr = Xs + l31 * SC_LD + 4 * half;
-    const float* wr = W + (size_t)(c * 32 + l31) * K + 4 * half;
+    const float* wr = W + ((size_t)c * (K / 8)) * 256 + (size_t)lane * 4;  // fragment-packed (st_pack_weight)
 #pragma unroll 8
     for (int kg = 0; kg < K / 8; ++kg) {
       const f32x4 a = *(const f32x4*)(xr + kg * 8);
-      const f32x4 b = *(const f32x4*)(wr + kg * 8);
+      const f32x4 b = *(const f32x4*)(wr + (size_t)kg * 256);
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
     }

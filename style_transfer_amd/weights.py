@@ -134,9 +134,9 @@ class ScorerWeights(_Packed):
         w2, b2 = fold_bn(siamese_sd["fc2.weight"], siamese_sd["fc2.bias"], siamese_sd["norm2.weight"],
                          siamese_sd["norm2.bias"], siamese_sd["norm2.running_mean"], siamese_sd["norm2.running_var"])
         w3, b3 = siamese_sd["fc3.weight"], siamese_sd["fc3.bias"]
-        c.s1_w, c.s1_wt, c.s1_b = self.dev(w1), self.dev(w1.t()), self.dev(b1)
-        c.s2_w, c.s2_wt, c.s2_b = self.dev(w2), self.dev(w2.t()), self.dev(b2)
-        c.s3_w, c.s3_wt, c.s3_b = self.dev(w3), self.dev(w3.t()), self.dev(b3)
+        c.s1_w, c.s1_wt, c.s1_b = self.packed(w1), self.packed(w1.t()), self.dev(b1)
+        c.s2_w, c.s2_wt, c.s2_b = self.packed(w2), self.packed(w2.t()), self.dev(b2)
+        c.s3_w, c.s3_wt, c.s3_b = self.packed(w3), self.packed(w3.t()), self.dev(b3)
         if predictor_sd is not None:
             u1, c1 = fold_bn(predictor_sd["fc1.weight"], predictor_sd["fc1.bias"], predictor_sd["norm1.weight"],
                              predictor_sd["norm1.bias"], predictor_sd["norm1.running_mean"], predictor_sd["norm1.running_var"])
@@ -146,5 +146,5 @@ class ScorerWeights(_Packed):
             u1p = torch.zeros(128, 256); u1p[:hid] = u1
             c1p = torch.zeros(128); c1p[:hid] = c1
             u2p = torch.zeros(256, 128); u2p[:, :hid] = predictor_sd["fc2.weight"]
-            c.p1_w, c.p1_wt, c.p1_b = self.dev(u1p), self.dev(u1p.t()), self.dev(c1p)
-            c.p2_w, c.p2_wt, c.p2_b = self.dev(u2p), self.dev(u2p.t()), self.dev(predictor_sd["fc2.bias"])
+            c.p1_w, c.p1_wt, c.p1_b = self.packed(u1p), self.packed(u1p.t()), self.dev(c1p)
+            c.p2_w, c.p2_wt, c.p2_b = self.packed(u2p), self.packed(u2p.t()), self.dev(predictor_sd["fc2.bias"])

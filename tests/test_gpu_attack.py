@@ -93,7 +93,8 @@ def test_attack_notnll_matches_reference(env, gold_notnll):
     ("nll", dict(), dict()),
     ("nll_one", dict(just_use_one=True), dict()),
     ("simplest", dict(not_nll=True, simplest_siamese=True, pos_victim_lr=0.2, neg_victim_lr=0.3), dict()),
-    ("p3n5", dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), dict(pos_num=3, neg_num=5)),
+    ("p3n5", dict(), dict(pos_num=3, neg_num=5)),
+    ("p4n4", dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), dict(pos_num=4, neg_num=4)),
 ])
 def test_attack_variants_match_reference(env, tag, flags, kw):
     path = os.path.join(GOLD, "attack_%s.npz" % tag)
@@ -153,3 +154,13 @@ def test_cli_full_yelp_test_set_batch256(env, gold_notnll, tmp_path, capsys):
     for k, s in enumerate(gold_notnll["subset"]):
         same += int(body(blocks[int(s)]) == body(ref[k]))
     assert same == len(ref), same
+
+
+def test_not_nll_with_unequal_counts_is_rejected_like_the_reference(env):
+    """siamese_contrastive.py:429 adds pos_loss [K+] to neg_loss [K-]: a RuntimeError unless K+ == K-."""
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet
+    data = AttackSet.from_json(env["files"], env["V"], pos_num=3, neg_num=5).subset([0, 1])
+    r = AttackRunner(env["ae"], env["scorer"], AttackConfig(not_nll=True, log_decodes=False), env["dev"])
+    with pytest.raises(ValueError, match="pos_num"):
+        r.run_batch(data, [0, 1])

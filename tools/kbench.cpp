@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
   {  // generator
     GemmArgs g = {};
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
-    const int sp = rp_splits(n, V, 16) < 4 ? 4 : rp_splits(n, V, 16);
+    const int sp = argc > 2 ? atoi(argv[2]) : rp_splits(n, V, 16);
     t = timeit([&] { launch_rp<EPI_ARGMAX>(g, n, sp, st); });
     printf("generator  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
   }
