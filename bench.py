@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=16384, help="sentences per GPU per step")
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
+    ap.add_argument("--tokens", default="zipf", choices=["zipf", "uniform", "real"],
+                    help="synthetic token ids: unigram (Zipfian) from word_to_id.txt counts, uniform in [4,V), or the "
+                         "1000 real yelp test sentences tiled to the batch size")
     ap.add_argument("--fixed-steps", action="store_true", help="no early exit at EOS: always 59 decode steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-decode", type=int, default=9)
@@ -94,7 +97,14 @@ def main():
                        iters_per_decode=a.iters_per_decode)
     runner = AttackRunner(ae, scorer, cfg, dev)
     B = a.batch
-    data = AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank)
+    from style_transfer_amd.data import load_word_counts
+    if a.tokens == "real":
+        files = [os.path.join(GOLD, "yelp", "neg10_pos10_test%d.json" % i) for i in (0, 1)]
+        real = AttackSet.from_json(files, ae.vocab)
+        data = real.subset([(i + 137 * rank) % len(real) for i in range(B)])
+    else:
+        counts = load_word_counts(os.path.join(GOLD, "yelp", "word_to_id.txt"), ae.vocab) if a.tokens == "zipf" else None
+        data = AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank, word_counts=counts)
     prep = runner.prepare(data)                       # tokens resident in HBM before the timed region
     gidx = torch.arange(B, device=dev) % 1000
 
@@ -134,10 +144,12 @@ def main():
             "value": world * B * a.steps / dt, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d), %d per GPU per step, flags --attack --not_nll "
-                                   "--pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
+            "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d; token ids: %s), %d per GPU per step, flags --attack "
+                                   "--not_nll --pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
                                    "surrogate AE checkpoint + shipped Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes off"
-                                   % (a.shape, B, "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS"),
+                                   % (a.shape, {"zipf": "unigram/Zipfian from word_to_id.txt counts", "uniform": "uniform in [4,V)",
+                                                "real": "the real yelp test set tiled"}[a.tokens], B,
+                                      "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS"),
                        "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
                        "mean_edit_iterations_per_sentence": n_iter_mean,
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,

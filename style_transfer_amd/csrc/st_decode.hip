@@ -5,6 +5,7 @@
 #include "st_rowpanel.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 void st_set_error(const char* fmt, ...) {
@@ -288,6 +289,8 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   int n_bound = B;
   int cur = 0;
   int steps = 0;
+  static const bool trace_steps = getenv("ST_TRACE_STEPS") != nullptr;  // debug: live rows per step on stderr
+  if (trace_steps) fprintf(stderr, "[st_decode] B=%d live:", B);
   for (int pos = 0; pos < T && n_bound > 0; ++pos) {
     const int* idx = ws.idx[cur];
     const int* n_dev = ws.cnt + cur;
@@ -302,7 +305,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
-      ST_TRY(launch_rp<EPI_QKV>(g, n_bound, rp_splits(n_bound, 768, 6), st));
+      ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, rp_splits(n_bound, 768, 3, 8), st)));
       hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
                          ws.att);
       ST_LAUNCH_CHECK();
@@ -320,7 +323,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         GemmArgs f1 = {};
         f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
         f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
-        ST_TRY(launch_rp<EPI_RELU>(f1, n_bound, rp_splits(n_bound, w->d_ff, 8), st));
+        ST_TRY((launch_rp<EPI_RELU, 8>(f1, n_bound, rp_splits(n_bound, w->d_ff, 4, 8), st)));
       }
       GemmArgs f2 = {};
       f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
@@ -346,8 +349,10 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       ST_HIP(hipMemcpyAsync(&live, ws.cnt + cur, sizeof(int), hipMemcpyDeviceToHost, st));
       ST_HIP(hipStreamSynchronize(st));
       n_bound = live;
+      if (trace_steps) fprintf(stderr, " %d", live);
     }
   }
+  if (trace_steps) fprintf(stderr, "\n");
   if (n_steps_host) *n_steps_host = steps;
   return ST_OK;
 }

@@ -122,7 +122,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     GemmArgs g = {};
     g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
     g.out = qkv; g.ldo = 768;
-    ST_TRY(launch_rp<EPI_BIAS>(g, R, rp_splits(R, 768, 6), st));
+    ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, rp_splits(R, 768, 3, 8), st)));
     hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
     ST_LAUNCH_CHECK();
     if (R >= RP_FUSE_MIN_ROWS) {
@@ -137,7 +137,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       GemmArgs f1 = {};
       f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
       f1.out = h; f1.ldo = w->d_ff;
-      ST_TRY(launch_rp<EPI_RELU>(f1, R, rp_splits(R, w->d_ff, 8), st));
+      ST_TRY((launch_rp<EPI_RELU, 8>(f1, R, rp_splits(R, w->d_ff, 4, 8), st)));
     }
     GemmArgs f2 = {};
     f2.X = h; f2.n_host = R; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256; f2.out = x; f2.ldo = 256; f2.resid = x;

@@ -12,13 +12,21 @@
 #pragma once
 #include "st_gemm.h"
 
-#define RP_LDS ((64 * ST_LDA + 4 * 64 * 4) * 4)
+// streaming outputs (written once, read by a later kernel): nontemporal stores keep them from evicting
+// the L2-resident weights
+#ifdef ST_NO_NT
+#define ST_STORE(ptr, v) (*(ptr) = (v))
+#else
+#define ST_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#endif
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
+#define RP_LDS ((64 * ST_LDA + 8 * 64 * 4) * 4)
+
+template <int EPI, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;                  // [64][ST_LDA]
-  float* red = smem + 64 * ST_LDA;   // [4 waves][64 rows][4]
+  float* red = smem + 64 * ST_LDA;   // [NW waves][64 rows][4]
   const int n = a.n_dev ? *a.n_dev : a.n_host;
   const int m0 = blockIdx.x * 64;
   if (m0 >= n) return;
@@ -27,8 +35,8 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
 
   // ---- X panel -> LDS (64 rows x 64 float4, 16 per thread), optional LayerNorm ----
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int f = tid + i * 256;
+  for (int i = 0; i < 64 / NW; ++i) {
+    const int f = tid + i * 64 * NW;
     const int r = f >> 6, c4 = f & 63;
     *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
   }
@@ -37,8 +45,8 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
     const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
     const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
 #pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) {
-      float* p = As + (wave * 16 + rr) * ST_LDA + lane * 4;
+    for (int rr = 0; rr < 64 / NW; ++rr) {
+      float* p = As + (wave * (64 / NW) + rr) * ST_LDA + lane * 4;
       *(f32x4*)p = layernorm256(*(f32x4*)p, ga, gb);
     }
     __syncthreads();
@@ -63,17 +71,17 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
       }
     }
 
-  // this workgroup's column blocks [b0, b1), this wave's: b0 + wave + 4*i
+  // this workgroup's column blocks [b0, b1), this wave's: b0 + wave + NW*i
   const int nblk = (a.N + 31) >> 5;
   const int per = (nblk + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per;
   const int b1 = min(nblk, b0 + per);
-  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) >> 2 : 0;
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + NW - 1) / NW : 0;
   const int total = cnt * 32;  // (block, kg) steps
   const float* Wl = a.W + (size_t)lane * 4;
   auto wload = [&](int g) -> f32x4 {
     g = min(g, total - 1);
-    const int blk = b0 + wave + 4 * (g >> 5);
+    const int blk = b0 + wave + NW * (g >> 5);
     return *(const f32x4*)(Wl + ((size_t)blk * 32 + (g & 31)) * 256);
   };
   f32x4 ring[8];
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
   float pre[2][16];  // RESID: residual (+ cross-attention constant), fetched while the block's MFMAs run
   for (int g0 = 0; g0 < total; g0 += 8) {
     if (EPI == EPI_RESID && (g0 & 31) == 0) {
-      const int col = min(((b0 + wave + 4 * (g0 >> 5)) << 5) + l31, a.N - 1);
+      const int col = min(((b0 + wave + NW * (g0 >> 5)) << 5) + l31, a.N - 1);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
     }
     if (((g0 + 8) & 31) == 0) {
       // ---- epilogue for this wave's column block ----
-      const int col = ((b0 + wave + 4 * (g0 >> 5)) << 5) + l31;
+      const int col = ((b0 + wave + NW * (g0 >> 5)) << 5) + l31;
       const bool colok = col < a.N;
       const float bv = (colok && a.bias) ? a.bias[col] : 0.0f;
 #pragma unroll
@@ -140,22 +148,22 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
             }
           } else if (row < n && colok) {
             if (EPI == EPI_BIAS) {
-              a.out[(size_t)row * a.ldo + col] = v;
+              ST_STORE(&a.out[(size_t)row * a.ldo + col], v);
             } else if (EPI == EPI_RELU) {
-              a.out[(size_t)row * a.ldo + col] = fmaxf(v, 0.0f);
+              ST_STORE(&a.out[(size_t)row * a.ldo + col], fmaxf(v, 0.0f));
             } else if (EPI == EPI_RESID) {
-              a.out[(size_t)row * a.ldo + col] = v + pre[mi][r];
+              ST_STORE(&a.out[(size_t)row * a.ldo + col], v + pre[mi][r]);
             } else if (EPI == EPI_DS) {
               const float sv = v * a.scale;
               const float pr = expf(sv - a.lse[row]) - (col == a.row_offset + row ? 1.0f : 0.0f);
               a.out[(size_t)row * a.ldo + col] = a.g[row] * pr * a.scale;
             } else if (EPI == EPI_QKV) {
               if (col < 256) {
-                a.q[(size_t)row * 256 + col] = v;
+                ST_STORE(&a.q[(size_t)row * 256 + col], v);
               } else {
                 const long s = a.idx[row];
                 float* base = (col < 512) ? a.kbase : a.vbase;
-                base[s * a.kv_stride + ((col - 256) & 255)] = v;
+                ST_STORE(&base[s * a.kv_stride + ((col - 256) & 255)], v);
               }
             }
           }
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
     if (tid < 64 && m0 + tid < n) {
       if (EPI == EPI_ARGMAX) {
         Top2 t = {red[tid * 4 + 0], __float_as_int(red[tid * 4 + 1]), red[tid * 4 + 2]};
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
           Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
           t = top2_merge(t, u);
         }
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
       } else {
         Lse t = {red[tid * 4 + 0], red[tid * 4 + 1]};
         float tg = red[tid * 4 + 2];
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
           Lse u = {red[(w * 64 + tid) * 4 + 0], red[(w * 64 + tid) * 4 + 1]};
           t = lse_merge(t, u);
           tg += red[(w * 64 + tid) * 4 + 2];
@@ -232,11 +240,11 @@ __global__ __launch_bounds__(256, 2) void rp_gemm_kernel(GemmArgs a) {
 // number of column splits: enough workgroups for ~2 rounds on 256 CUs x 2 workgroups, at most max_splits,
 // never fewer than one 32-column block per wave; among the admissible counts prefer the one whose
 // per-wave block count is best balanced (a workgroup lasts as long as its busiest wave).
-static inline int rp_splits(int n_rows, int N, int max_splits) {
+static inline int rp_splits(int n_rows, int N, int max_splits, int nw = 4) {
   const int panels = (n_rows + 63) / 64;
   const int nblk = (N + 31) / 32;
   int want = (1024 + panels - 1) / (panels > 0 ? panels : 1);
-  const int cap = (nblk + 3) / 4;
+  const int cap = (nblk + nw - 1) / nw;
   if (want > cap) want = cap;
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
@@ -244,8 +252,8 @@ static inline int rp_splits(int n_rows, int N, int max_splits) {
   double best_eff = 0.0;
   for (int s = want; s <= max_splits && s <= cap && s <= want * 2; ++s) {
     const int per = (nblk + s - 1) / s;          // blocks per workgroup
-    const int busiest = (per + 3) / 4;           // blocks of the busiest wave
-    const double eff = (double)nblk / ((double)s * 4.0 * busiest);
+    const int busiest = (per + nw - 1) / nw;     // blocks of the busiest wave
+    const double eff = (double)nblk / ((double)s * nw * busiest);
     if (eff > best_eff + 0.02) {
       best_eff = eff;
       best = s;
@@ -254,16 +262,16 @@ static inline int rp_splits(int n_rows, int N, int max_splits) {
   return best;
 }
 
-template <int EPI>
+template <int EPI, int NW = 4>
 static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
+    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
     attr_done = true;
   }
   if (n_bound <= 0) return ST_OK;
   dim3 grid((n_bound + 63) / 64, splits);
-  hipLaunchKernelGGL(rp_gemm_kernel<EPI>, grid, dim3(256), RP_LDS, st, a);
+  hipLaunchKernelGGL((rp_gemm_kernel<EPI, NW>), grid, dim3(64 * NW), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + mi * 32 + mfma32_row(r, lane);
-        if (row < n) a.out[(size_t)row * a.ldo + col] = acc[mi][nb][r];
+        if (row < n) ST_STORE(&a.out[(size_t)row * a.ldo + col], acc[mi][nb][r]);
       }
   }
 }
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
         const int lr = mi * 32 + mfma32_row(r, lane);
         const float v = acc[mi][nb][r];
         As[lr * ST_LDA + col] = v;
-        if (m0 + lr < n) a.x[(size_t)(m0 + lr) * 256 + col] = v;
+        if (m0 + lr < n) ST_STORE(&a.x[(size_t)(m0 + lr) * 256 + col], v);
       }
   }
   __syncthreads();
@@ -513,11 +521,7 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + mi * 32 + mfma32_row(r, lane);
-#ifdef ST_ABLATE_HSTORE
-          if (row < n && ac[r] == 12345.678f) a.h[(size_t)row * a.d_ff + col] = fmaxf(ac[r] + bv, 0.0f);
-#else
-          if (row < n) a.h[(size_t)row * a.d_ff + col] = fmaxf(ac[r] + bv, 0.0f);
-#endif
+          if (row < n) ST_STORE(&a.h[(size_t)row * a.d_ff + col], fmaxf(ac[r] + bv, 0.0f));
         }
       }
       acc0 = (f32x16){0};

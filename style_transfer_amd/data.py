@@ -23,6 +23,18 @@ def load_word_dict_info(word_dict_file: str, max_num: int):
     return id_to_word, len(id_to_word)
 
 
+def load_word_counts(word_dict_file: str, vocab_size: int):
+    """counts column of word_to_id.txt for the first vocab_size entries (specials without a count -> 0)"""
+    counts = []
+    with open(word_dict_file, "r") as f:
+        for line in f:
+            it = line.strip().split("\t")
+            counts.append(int(it[1]) if len(it) > 1 else 0)
+            if len(counts) == vocab_size:
+                break
+    return np.asarray(counts, np.int64)
+
+
 def canonical_ids(id_to_word):
     """id -> first id spelling the same word (text equality == canonical-id equality); None if identity."""
     first = {}
@@ -87,18 +99,41 @@ class AttackSet:
         return cls(origin, like, unlike, labels)
 
     @classmethod
-    def synthetic(cls, n, vocab_size, shape="yelp", n_pos=10, n_neg=10, seed=1234):
+    def synthetic(cls, n, vocab_size, shape="yelp", n_pos=10, n_neg=10, seed=1234, word_counts=None):
         """SURVEY.md §8d synthetic sets: yelp-shaped origins 6-15 tokens (mean ~10.3), refs/sims 1-16;
-        amazon-shaped origins 8-15, refs/sims 8-31; ids uniform in [4, V)."""
+        amazon-shaped origins 8-15, refs/sims 8-31; ids uniform in [4, V), or — when word_counts (the
+        counts column of word_to_id.txt) is given — drawn from that unigram (Zipfian) distribution."""
         rng = np.random.default_rng(seed)
+        if word_counts is not None:
+            pr = np.asarray(word_counts[4:vocab_size], np.float64)
+            pr = pr / pr.sum()
+            pool = (rng.choice(len(pr), size=1 << 22, p=pr) + 4).astype(np.int64)
+            cursor = [0]
+
+            class _Z:
+                @staticmethod
+                def integers(lo, hi, size=None):
+                    if lo == 4 and hi == vocab_size:
+                        k = int(size)
+                        if cursor[0] + k > len(pool):
+                            cursor[0] = 0
+                        out = pool[cursor[0]:cursor[0] + k]
+                        cursor[0] += k
+                        return out
+                    return rng.integers(lo, hi, size)
+
+                normal = rng.normal
+            tok = _Z
+        else:
+            tok = rng
         if shape == "yelp":
             olen = np.clip(rng.normal(10.3, 2.6, n).round().astype(int), 6, 15)
             rlo, rhi = 1, 16
         else:
             olen = rng.integers(8, 16, n)
             rlo, rhi = 8, 31
-        origin = [rng.integers(4, vocab_size, l).tolist() for l in olen]
-        mk = lambda k: [[rng.integers(4, vocab_size, rng.integers(rlo, rhi + 1)).tolist() for _ in range(k)] for _ in range(n)]
+        origin = [tok.integers(4, vocab_size, l).tolist() for l in olen]
+        mk = lambda k: [[tok.integers(4, vocab_size, rng.integers(rlo, rhi + 1)).tolist() for _ in range(k)] for _ in range(n)]
         return cls(origin, mk(n_pos), mk(n_neg))
 
     def subset(self, idx):

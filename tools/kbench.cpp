@@ -87,6 +87,8 @@ int main(int argc, char** argv) {
     const int sp = rp_splits(n, DFF, 8);
     t = timeit([&] { launch_rp<EPI_RELU>(g, n, sp, st); });
     printf("ffn1       n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * DFF / t / 1e12);
+    t = timeit([&] { launch_rp<EPI_RELU, 8>(g, n, sp, st); });
+    printf("ffn1 NW=8  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * DFF / t / 1e12);
   }
   {  // QKV as plain BIAS store to [n,768]
     GemmArgs g = {};
@@ -94,6 +96,8 @@ int main(int argc, char** argv) {
     const int sp = rp_splits(n, 768, 6);
     t = timeit([&] { launch_rp<EPI_BIAS>(g, n, sp, st); });
     printf("qkv(bias)  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
+    t = timeit([&] { launch_rp<EPI_BIAS, 8>(g, n, sp, st); });
+    printf("qkv NW=8   n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
   }
   {  // O-proj RESID
     GemmArgs g = {};
