@@ -137,6 +137,58 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
   out[(size_t)r * 256 + h * 64 + lane] = (o0 + o1) + (o2 + o3);
 }
 
+
+// Short-prefix variant (pos < 16, i.e. almost every step of a yelp decode): ONE wave per row handles all
+// four heads, lane = (head h = lane>>4, key j = lane&15), so all 64 lanes work in the score/softmax
+// phase (the general kernel above keeps 64-pos-1 lanes idle); in the PV phase lane owns output dims
+// 4*lane..4*lane+3, which belong to head lane>>4 again.
+__global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
+                                                          const float* __restrict__ vbase, long kv_stride,
+                                                          const int* __restrict__ idx, const int* __restrict__ n_dev,
+                                                          int pos, float* __restrict__ out) {
+  __shared__ __align__(16) float qs[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= *n_dev) return;
+  const int h = lane >> 4, j = lane & 15;
+  *(f32x4*)(&qs[wave][lane * 4]) = *(const f32x4*)(q + (size_t)r * 256 + lane * 4);
+  __builtin_amdgcn_wave_barrier();
+  const long s = idx[r];
+  const float* K = kbase + s * kv_stride;
+  const float* V = vbase + s * kv_stride;
+  float sc = -INFINITY;
+  if (j <= pos) {
+    const float* kr = K + (size_t)j * 256 + h * 64;
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4 kv = *(const f32x4*)(kr + d);
+      const f32x4 qv = *(const f32x4*)(&qs[wave][h * 64 + d]);
+      acc = fmaf(qv.x, kv.x, acc);
+      acc = fmaf(qv.y, kv.y, acc);
+      acc = fmaf(qv.z, kv.z, acc);
+      acc = fmaf(qv.w, kv.w, acc);
+    }
+    sc = acc * 0.125f;
+  }
+  float m = sc;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const float e = j <= pos ? expf(sc - m) : 0.0f;
+  float sum = e;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float p = e / sum;
+  f32x4 o4 = {0, 0, 0, 0};
+  const int base = lane & 48;
+  for (int jj = 0; jj <= pos; ++jj) {
+    const float pj = __shfl(p, base + jj, 64);
+    const f32x4 v4 = *(const f32x4*)(V + (size_t)jj * 256 + lane * 4);
+    o4 += pj * v4;
+  }
+  *(f32x4*)(out + (size_t)r * 256 + lane * 4) = o4;
+}
+
 // ------------------------------------------------------------------------------------------------
 // merge the generator's per-split (best, index, second) partials; emit the token; keep the sentence
 // live unless it produced EOS/PAD (early exit) or this was the last step.
@@ -306,8 +358,12 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
       ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, rp_splits(n_bound, 768, 3, 8), st)));
-      hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
-                         ws.att);
+      if (pos < 16)
+        hipLaunchKernelGGL(attn_step16_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
+                           n_dev, pos, ws.att);
+      else
+        hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
+                           ws.att);
       ST_LAUNCH_CHECK();
       if (n_bound >= RP_FUSE_MIN_ROWS) {
         OFArgs of = {};

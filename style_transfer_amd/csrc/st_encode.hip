@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
   const int s = blockIdx.x;
   const int r0 = off[s], len = off[s + 1] - r0;
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-  if (len <= 0) return;
+  if (len <= 16) return;  // short sentences: enc_attn16_kernel
   // this lane's key row (head slice) stays in registers for all queries
   f32x4 kreg[16];
   if (lane < len) {
@@ -54,6 +54,56 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
     float o = 0.0f;
     for (int j = 0; j < len; ++j) o = fmaf(__shfl(p, j, 64), qkv[(size_t)(r0 + j) * 768 + 512 + h * 64 + lane], o);
     out[(size_t)(r0 + i) * 256 + h * 64 + lane] = o;
+  }
+}
+
+// Sentences of <= 16 tokens (all of yelp): ONE wave per sentence handles the four heads, lane = (head
+// lane>>4, key lane&15); K and V slices of the sentence stay in registers for all its queries; in the PV
+// phase lane owns output dims 4*lane..4*lane+3 (head lane>>4 again).
+__global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
+                                                         int n_sent, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_sent) return;
+  const int r0 = off[s], len = off[s + 1] - r0;
+  if (len <= 0 || len > 16) return;
+  const int h = lane >> 4, j = lane & 15, base = lane & 48;
+  f32x4 kreg[16], vreg[16];
+  {
+    const float* kr = qkv + (size_t)(r0 + min(j, len - 1)) * 768 + 256 + h * 64;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) kreg[d] = *(const f32x4*)(kr + d * 4);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj)
+      vreg[jj] = *(const f32x4*)(qkv + (size_t)(r0 + min(jj, len - 1)) * 768 + 512 + lane * 4);
+  }
+  for (int i = 0; i < len; ++i) {
+    const float* qr = qkv + (size_t)(r0 + i) * 768 + h * 64;
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      const f32x4 qv = *(const f32x4*)(qr + d * 4);
+      acc = fmaf(qv.x, kreg[d].x, acc);
+      acc = fmaf(qv.y, kreg[d].y, acc);
+      acc = fmaf(qv.z, kreg[d].z, acc);
+      acc = fmaf(qv.w, kreg[d].w, acc);
+    }
+    const float sc = j < len ? acc * 0.125f : -INFINITY;
+    float m = sc;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float e = j < len ? expf(sc - m) : 0.0f;
+    float sum = e;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float p = e / sum;
+    f32x4 o4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const float pj = __shfl(p, base + jj, 64);  // exactly 0 for jj >= len
+      o4 += pj * vreg[jj];
+    }
+    *(f32x4*)(out + (size_t)(r0 + i) * 256 + lane * 4) = o4;
   }
 }
 
@@ -123,7 +173,8 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
     g.out = qkv; g.ldo = 768;
     ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, rp_splits(R, 768, 3, 8), st)));
-    hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+    hipLaunchKernelGGL(enc_attn16_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
+    if (max_sent_len > 16) hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
     ST_LAUNCH_CHECK();
     if (R >= RP_FUSE_MIN_ROWS) {
       OFArgs of = {};

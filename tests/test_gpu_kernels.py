@@ -148,6 +148,7 @@ def test_encode_latent(dev, ae, ae_sd):
     from style_transfer_amd import ops
     from style_transfer_amd.data import pack_sentences
     sents = some_sentences(40) + [[], [5]]
+    sents += [sents[0] + sents[1], (sents[2] * 8)[:59], sents[3][:16], (sents[4] * 3)[:17]]   # > 16 tokens: general kernel
     tok, pos, off, mx = pack_sentences(sents)
     t = lambda v: torch.from_numpy(v).to(dev)
     got = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx).cpu().numpy()
