@@ -143,10 +143,14 @@ print("rank", rank, "ok")
 
 def test_two_rank_gather_reassembles_global_order(tmp_path):
     """N > 1 path: contiguous shards, all_gather of ragged per-shard records, global order restored (gloo)."""
+    import socket
+    with socket.socket() as so:          # a free rendezvous port (a fixed one can collide with another run)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     script = tmp_path / "w.py"
     script.write_text(GATHER_WORKER % dict(root=ROOT))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
