@@ -291,14 +291,19 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int K = a.K, kgs = K >> 3, nchunk = K >> 8;
+  // split-K (gridDim.y > 1): this workgroup sums chunks [c_begin, c_end) into slab blockIdx.y of `out`
+  // ([gridDim.y][n_host][ldo]; summed by slab_reduce_kernel); the caller passes bias == resid == null
+  const int cps = (nchunk + gridDim.y - 1) / gridDim.y;
+  const int c_begin = blockIdx.y * cps, c_end = min(nchunk, c_begin + cps);
+  float* outp = a.out + (size_t)blockIdx.y * a.n_host * a.ldo;
   const float* W0 = a.W + ((size_t)wave * kgs) * 256 + (size_t)lane * 4;        // block `wave`
   const float* W1 = a.W + ((size_t)(wave + 4) * kgs) * 256 + (size_t)lane * 4;  // block `wave + 4`
-  const int total = kgs;
+  const int total = max(c_end * 32, 1);
   f32x4 r0[4], r1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    r0[j] = *(const f32x4*)(W0 + (size_t)min(j, total - 1) * 256);
-    r1[j] = *(const f32x4*)(W1 + (size_t)min(j, total - 1) * 256);
+    r0[j] = *(const f32x4*)(W0 + (size_t)min(c_begin * 32 + j, total - 1) * 256);
+    r1[j] = *(const f32x4*)(W1 + (size_t)min(c_begin * 32 + j, total - 1) * 256);
   }
   // accumulators start from bias (+ residual + cross constant): the fetch overlaps the whole K loop
   f32x16 acc[2][2];
@@ -320,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
       }
   }
   const float* Ab = As + l31 * ST_LDA + 4 * half;
-  for (int c = 0; c < nchunk; ++c) {
-    if (c) __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    if (c > c_begin) __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int f = tid + i * 256;
@@ -357,13 +362,24 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + mi * 32 + mfma32_row(r, lane);
-        if (row < n) ST_STORE(&a.out[(size_t)row * a.ldo + col], acc[mi][nb][r]);
+        if (row < n) ST_STORE(&outp[(size_t)row * a.ldo + col], acc[mi][nb][r]);
       }
   }
 }
 
+// out[i] (+)= sum_y slab[y][i]   (split-K combine; float4 per thread)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, size_t stride4,
+                                                          float* __restrict__ out, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = *(const f32x4*)(slab + i * 4);
+  for (int y = 1; y < nsplit; ++y) s += *(const f32x4*)(slab + ((size_t)y * stride4 + i) * 4);
+  *(f32x4*)(out + i * 4) = s;
+}
+
 template <int EPI>
-static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st) {
+static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st, int ksplit = 1) {
   static bool attr_done = false;
   if (!attr_done) {
     ST_HIP(hipFuncSetAttribute((const void*)rp_kchunk_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
@@ -374,7 +390,7 @@ static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st) {
     st_set_error("rp_kchunk: needs N == 256 and K a multiple of 256 (N=%d K=%d)", a.N, a.K);
     return ST_EINVAL;
   }
-  hipLaunchKernelGGL(rp_kchunk_kernel<EPI>, dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
+  hipLaunchKernelGGL(rp_kchunk_kernel<EPI>, dim3((n_bound + 63) / 64, ksplit), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

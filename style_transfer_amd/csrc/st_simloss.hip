@@ -11,6 +11,7 @@
 
 #define SL_SPLITS 4
 #define SL_CHUNK 1024
+#define SL_KSPLIT 16
 
 // u = x / max(||x||, 1e-8), nrm = max(||x||, 1e-8); wave per row.  ut (optional) = u transposed [256, n]
 __global__ __launch_bounds__(256) void unit_rows_kernel(const float* __restrict__ x, int n, float* __restrict__ u,
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void unit_rows_bwd_kernel(const float* __restr
 static inline size_t sl_align(size_t v) { return (v + 255) / 256 * 256; }
 
 struct SlWs {
-  float *ou, *ku, *kup, *kut, *on, *kn, *dou, *dku, *ds;
+  float *ou, *ku, *kup, *kut, *kutp, *on, *kn, *dou, *dku, *ds, *slab;
   float4* partial;
   size_t total;
 };
@@ -81,6 +82,8 @@ static SlWs sl_carve(int Bq, int Bk, char* base) {
   w.ku = (float*)take((size_t)Bk * 1024);
   w.kup = (float*)take(rp_packed_floats(Bk, 256) * 4);
   w.kut = (float*)take((size_t)Bk * 1024);
+  w.kutp = (float*)take((size_t)Bk * 1024);
+  w.slab = (float*)take((size_t)SL_KSPLIT * SL_CHUNK * 1024);
   w.on = (float*)take((size_t)Bq * 4);
   w.kn = (float*)take((size_t)Bk * 4);
   w.dou = (float*)take((size_t)Bq * 1024);
@@ -142,6 +145,11 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
   ST_LAUNCH_CHECK();
   hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((rp_packed_floats(Bk, 256) / 4 + 255) / 256)), dim3(256), 0, st, w.ku, Bk, 256, w.kup);
   ST_LAUNCH_CHECK();
+  const bool splitk = (Bk % 256 == 0);   // d_ou = dS . ku on the row-panel kernel, K = Bk split over workgroups
+  if (splitk) {
+    hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)(((size_t)8 * (Bk >> 3) * 64 + 255) / 256)), dim3(256), 0, st, w.kut, 256, Bk, w.kutp);
+    ST_LAUNCH_CHECK();
+  }
   ST_HIP(hipMemsetAsync(w.dku, 0, (size_t)Bk * 1024, st));
   for (int r0 = 0; r0 < Bq; r0 += SL_CHUNK) {
     const int rows = (Bq - r0 < SL_CHUNK) ? Bq - r0 : SL_CHUNK;
@@ -153,7 +161,22 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
     // d_ou[chunk] = dS . ku   (W = ku^T [256, Bk])
     GemmArgs b = {};
     b.X = w.ds; b.n_host = rows; b.K = Bk; b.W = w.kut; b.N = 256; b.out = w.dou + (size_t)r0 * 256; b.ldo = 256;
-    ST_TRY(launch_kloop<EPI_BIAS>(b, rows, st));
+    if (splitk) {
+      const int nchunk = Bk >> 8;
+      int ks = SL_KSPLIT < nchunk ? SL_KSPLIT : nchunk;
+      while (ks > 1 && ((rows + 63) / 64) * ks > 1024) ks >>= 1;   // no more workgroups than ~2 rounds
+      b.W = w.kutp;
+      b.out = ks > 1 ? w.slab : w.dou + (size_t)r0 * 256;
+      ST_TRY(launch_rp_kchunk<EPI_BIAS>(b, rows, st, ks));
+      if (ks > 1) {
+        const size_t n4 = (size_t)rows * 64;
+        hipLaunchKernelGGL(slab_reduce_kernel<0>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.slab, ks, n4,
+                           w.dou + (size_t)r0 * 256, n4);
+        ST_LAUNCH_CHECK();
+      }
+    } else {
+      ST_TRY(launch_kloop<EPI_BIAS>(b, rows, st));
+    }
     // d_ku += dS^T . ou[chunk]   (X given transposed: dS [K=rows, n=Bk]; W given transposed: ou chunk [K=rows, 256])
     GemmArgs c = {};
     c.X = w.ds; c.ldx = Bk; c.n_host = Bk; c.K = rows; c.W = w.ou + (size_t)r0 * 256; c.ldw = 256; c.N = 256;

@@ -302,3 +302,15 @@ def test_large_batch_paths_equal_small_batch(dev, ae, ae_sd):
     ids_big, _, _ = ops.greedy_decode(ae, big)
     same = (ids_big.view(450, len(sents), 59) == ids_small[None]).all(dim=2).all(dim=0)
     assert int(same.sum().item()) >= len(sents) - 1, same.cpu().tolist()
+
+
+def test_constraint_loss_wrapper_single_rank(dev):
+    """contrastive.constraint_loss_and_grads on one rank with the HIP kernels == reference torch autograd"""
+    from style_transfer_amd.contrastive import constraint_loss_and_grads
+    g = gold("simloss_b128.npz")
+    ori = torch.from_numpy(g["ori"]).to(dev)
+    like = torch.from_numpy(g["like"]).to(dev)
+    loss, d_ori, d_like = constraint_loss_and_grads(ori, like, float(g["tau"]))
+    assert abs(loss - float(g["loss"])) < 1e-4
+    assert relerr(d_ori.cpu().numpy(), g["d_ori"]) < 1e-3
+    assert relerr(d_like.cpu().numpy(), g["d_like"]) < 1e-3
