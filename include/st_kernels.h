@@ -152,10 +152,13 @@ int st_gemm_argmax(const float* h, const float* ln_a, const float* ln_b, const f
  * as texts (prefix up to the first EOS/PAD, ids >= vocab -> UNK, ids mapped through `canon`
  * (id -> first id with the same word) when canon != NULL).  If different: acc_ids <- new_ids,
  * changed[s] = 1, n_changes[s] += 1, and active[s] <- 0 once n_changes[s] >= max_change.
- * rec_ids (may be NULL) [B,T] receives the accepted row after this iteration.                   */
+ * rec_ids (may be NULL) [B,T] receives the accepted row after this iteration.
+ * confirm_ids (may be NULL; --retext, siamese_contrastive.py:819-825): decode of the RE-ENCODED new text;
+ * when given, a change is accepted only if confirm_ids spells the same text as new_ids.          */
 int st_accept_changes(const int32_t* new_ids, int32_t* acc_ids, int T, int B, int vocab, int unk,
                       int eos, int pad, const int32_t* canon, int max_change, int32_t* n_changes,
-                      uint8_t* changed, uint8_t* active, int32_t* rec_ids, void* stream);
+                      uint8_t* changed, uint8_t* active, int32_t* rec_ids, const int32_t* confirm_ids,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (5) In-batch InfoNCE similarity loss (train_ae_model_constraint, siamese_contrastive.py:1060-1069):

@@ -148,6 +148,8 @@ def run_attack(subset, flags, ckpt, tag, threads):
     ids = np.zeros((S, I, T), np.int32)
     gap = np.zeros((S, I, T), np.float32)
     loss = np.zeros((S, I), np.float32)
+    re_ids = np.zeros((S, I, T), np.int32)
+    re_latent = np.zeros((S, I, 256), np.float32)
     kp = per_sentence[0]["like_latent"].shape[0] if per_sentence[0]["like_latent"] is not None else 0
     kn = per_sentence[0]["unlike_latent"].shape[0] if per_sentence[0]["unlike_latent"] is not None else 0
     like = np.zeros((S, kp, 256), np.float32)
@@ -156,8 +158,14 @@ def run_attack(subset, flags, ckpt, tag, threads):
     for s, ps in enumerate(per_sentence):
         d0 = ps["decodes"][0]
         init_latent[s], init_ids[s], init_gap[s] = d0["latent"][0], d0["ids"][0], d0["gap"][0]
-        n_iter[s] = len(ps["decodes"]) - 1
-        for it, d in enumerate(ps["decodes"][1:]):
+        main = ps["decodes"][1:]
+        if flags.get("retext"):
+            # retext() decodes the re-encoded text right after every main decode (siamese_contrastive.py:849)
+            re_dec, main = main[1::2], main[0::2]
+            for it, d in enumerate(re_dec):
+                re_ids[s, it], re_latent[s, it] = d["ids"][0], d["latent"][0]
+        n_iter[s] = len(main)
+        for it, d in enumerate(main):
             lat[s, it], ids[s, it], gap[s, it], grad[s, it] = d["latent"][0], d["ids"][0], d["gap"][0], d["grad"][0]
             loss[s, it] = ps["losses"][it]
         if kp:
@@ -174,7 +182,7 @@ def run_attack(subset, flags, ckpt, tag, threads):
     np.savez_compressed(os.path.join(GOLD, "attack_%s.npz" % tag), subset=np.asarray(subset, np.int32), n_iter=n_iter,
                         init_latent=init_latent, init_ids=init_ids, init_gap=init_gap, latent=lat, grad=grad, ids=ids,
                         gap=gap, loss=loss, like_latent=like, unlike_latent=unlike, lr=lr, enc_src=enc_src,
-                        enc_latent=enc_latent, ref_seconds=np.float32(dt), ref_threads=np.int32(threads))
+                        enc_latent=enc_latent, re_ids=re_ids, re_latent=re_latent, ref_seconds=np.float32(dt), ref_threads=np.int32(threads))
     with open(os.path.join(GOLD, "attack_%s_log.txt" % tag), "w") as f:
         for ln in lines:
             f.write("INFO:siamese_contrastive.py:print_and_log:1592 - " + ln + "\n")
@@ -217,6 +225,8 @@ if __name__ == "__main__":
     elif a.what == "main":
         subset = list(range(a.n)) + list(range(500, 500 + a.n))
         run_attack(subset, dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "notnll", a.threads)
+    elif a.what == "retext":
+        run_attack([0, 1, 2, 3, 500, 501, 502, 503], dict(not_nll=True, retext=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "retext", a.threads)
     elif a.what == "variants":
         sub = [0, 1, 2, 500, 501, 502]
         if not os.path.exists(os.path.join(GOLD, "attack_nll.npz")):

@@ -79,8 +79,6 @@ class AttackRunner:
     def __init__(self, ae, scorer, cfg: AttackConfig, device):
         if cfg.victim_optimizer != "Adam":
             raise NotImplementedError("--victim_optimizer %s: only Adam has a kernel (the reference default, main.py:100)" % cfg.victim_optimizer)
-        if cfg.retext:
-            raise NotImplementedError("--retext is not implemented yet (SURVEY.md §8f rank 2)")
         self.ae, self.scorer, self.cfg, self.device = ae, scorer, cfg, device
         self.ws = ops.DecodeWorkspace(device)
         self.canon = None
@@ -116,6 +114,22 @@ class AttackRunner:
         c = self.cfg
         return ops.greedy_decode(self.ae, latent, c.max_sequence_length, c.id_bos, c.id_eos, c.id_pad,
                                  early_exit=c.early_exit, sync_every=c.sync_every, want_gap=want_gap, ws=self.ws)
+
+    def reencode(self, ids):
+        """--retext (siamese_contrastive.py:842-855): decoded ids [n,T] -> text -> ids -> latent.  The text
+        is the id prefix before the first EOS/PAD (data.py:43-52) and word <-> id is one-to-one, so the
+        re-encoded sentence is that prefix; packing happens on the device (torch indexing = plumbing)."""
+        c = self.cfg
+        n, T = ids.shape
+        term = (ids == c.id_eos) | (ids == c.id_pad)
+        lens = torch.where(term.any(1), term.int().argmax(1), torch.full((n,), T, device=ids.device, dtype=torch.int64))
+        ar = torch.arange(T, device=ids.device)
+        mask = ar[None, :] < lens[:, None]
+        tokens = ids[mask].to(torch.int32).contiguous()
+        tok_pos = ar.to(torch.int32)[None, :].expand(n, T)[mask].contiguous()
+        off = torch.zeros(n + 1, dtype=torch.int32, device=ids.device)
+        off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+        return ops.encode_latent(self.ae, tokens, tok_pos, off, n, int(lens.max().item()) if n else 0, ws=self.ws)
 
     # -- one batch --------------------------------------------------------------------------------
     def run_batch(self, batch: AttackSet, global_index) -> AttackResult:
@@ -161,7 +175,7 @@ class AttackRunner:
         want_gap = c.want_gap or c.want_trace
         tr = {k: [] for k in ("latent", "grad", "loss", "ids", "gap")} if c.want_trace else None
         max_change = (1 << 30) if c.dance else c.attack_max_change
-        C = max(1, min(c.iters_per_decode, I))
+        C = 1 if c.retext else max(1, min(c.iters_per_decode, I))   # --retext: the latent itself depends on the decodes
         torch.cuda.synchronize(dev)
         tm["setup_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()
@@ -198,6 +212,12 @@ class AttackRunner:
                 if gap is not None:
                     init_gap = torch.zeros(B, T, device=dev).index_copy_(0, live, gap[0])
                 k0 = 1
+            re_ids = re_lat = None
+            if c.retext:
+                re_lat = self.reencode(ids[k0])
+                re_ids_live, _, _ = self.decode(re_lat)
+                re_ids = torch.zeros(B, T, dtype=torch.int32, device=dev)
+                re_ids.index_copy_(0, live, re_ids_live)
             for j in range(cn):
                 it = it0 + j
                 was_active[it] = active
@@ -206,7 +226,13 @@ class AttackRunner:
                 still = active.bool()
                 final_latent[live] = torch.where(still[live, None], snaps[k0 + j], final_latent[live])
                 ops.accept_changes(new_ids, acc_ids, self.ae.vocab, n_changes, changed[it], active, max_change=max_change,
-                                   unk=c.id_unk, eos=c.id_eos, pad=c.id_pad, canon=self.canon, rec_ids=iter_ids[it])
+                                   unk=c.id_unk, eos=c.id_eos, pad=c.id_pad, canon=self.canon, rec_ids=iter_ids[it],
+                                   confirm_ids=re_ids)
+                if c.retext:
+                    # accepted: ori_latent.data = re_latent.data (siamese_contrastive.py:826); Adam state carries on
+                    acc_live = changed[it].bool()[live]
+                    ori[live] = torch.where(acc_live[:, None], re_lat, ori[live])
+                    final_latent[live] = torch.where(acc_live[:, None], re_lat, final_latent[live])
                 if tr is not None:
                     tr["ids"].append(new_ids.cpu().numpy().copy())
                     tr["gap"].append(torch.zeros(B, T, device=dev).index_copy_(0, live, gap[k0 + j]).cpu().numpy())

@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void accept_kernel(const int32_t* __restrict__
                                                      int T, int B, int vocab, int unk, int eos, int pad,
                                                      const int32_t* __restrict__ canon, int max_change,
                                                      int32_t* __restrict__ n_changes, uint8_t* __restrict__ changed,
-                                                     uint8_t* __restrict__ active, int32_t* __restrict__ rec_ids) {
+                                                     uint8_t* __restrict__ active, int32_t* __restrict__ rec_ids,
+                                                     const int32_t* __restrict__ confirm_ids) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= B) return;
   const bool live = active[s] != 0;
@@ -36,6 +37,23 @@ __global__ __launch_bounds__(256) void accept_kernel(const int32_t* __restrict__
         break;
       }
     }
+    if (diff && confirm_ids) {
+      // --retext (siamese_contrastive.py:819-825): the new text counts only if re-encoding and re-decoding
+      // it reproduces it (re_generator_text == generator_text)
+      const int32_t* cf = confirm_ids + (size_t)s * T;
+      for (int i = 0; i < T; ++i) {
+        const int a = nw[i], b = cf[i];
+        const bool ea = (a == eos || a == pad), eb = (b == eos || b == pad);
+        if (ea || eb) {
+          if (ea != eb) diff = false;
+          break;
+        }
+        if (canon_id(a, vocab, unk, canon) != canon_id(b, vocab, unk, canon)) {
+          diff = false;
+          break;
+        }
+      }
+    }
     if (diff) {
       for (int i = 0; i < T; ++i) ac[i] = nw[i];
       const int k = n_changes[s] + 1;
@@ -50,12 +68,12 @@ __global__ __launch_bounds__(256) void accept_kernel(const int32_t* __restrict__
 
 extern "C" int st_accept_changes(const int32_t* new_ids, int32_t* acc_ids, int T, int B, int vocab, int unk, int eos,
                                  int pad, const int32_t* canon, int max_change, int32_t* n_changes, uint8_t* changed,
-                                 uint8_t* active, int32_t* rec_ids, void* stream) {
+                                 uint8_t* active, int32_t* rec_ids, const int32_t* confirm_ids, void* stream) {
   ST_CHECK_ARG(B >= 0 && T >= 1, "B=%d T=%d", B, T);
   if (B == 0) return ST_OK;
   ST_CHECK_ARG(new_ids && acc_ids && n_changes && changed && active, "NULL buffer");
   hipLaunchKernelGGL(accept_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, new_ids, acc_ids, T, B,
-                     vocab, unk, eos, pad, canon, max_change, n_changes, changed, active, rec_ids);
+                     vocab, unk, eos, pad, canon, max_change, n_changes, changed, active, rec_ids, confirm_ids);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

@@ -138,12 +138,12 @@ def gemm_argmax(h, W, b, ln_a=None, ln_b=None, packed=None):
 
 
 def accept_changes(new_ids, acc_ids, vocab, n_changes, changed, active, max_change=7, unk=1, eos=3, pad=0,
-                   canon=None, rec_ids=None):
+                   canon=None, rec_ids=None, confirm_ids=None):
     B, T = new_ids.shape
     assert new_ids.dtype == torch.int32 and acc_ids.dtype == torch.int32 and new_ids.is_contiguous() and acc_ids.is_contiguous()
     check(lib().st_accept_changes(new_ids.data_ptr(), acc_ids.data_ptr(), T, B, vocab, unk, eos, pad, _p(canon),
                                   max_change, n_changes.data_ptr(), changed.data_ptr(), active.data_ptr(),
-                                  _p(rec_ids), _stream()), "st_accept_changes")
+                                  _p(rec_ids), _p(confirm_ids), _stream()), "st_accept_changes")
 
 
 def simloss_fwd(ori, like, tau=0.1, row_offset=0):

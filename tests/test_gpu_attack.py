@@ -95,6 +95,7 @@ def test_attack_notnll_matches_reference(env, gold_notnll):
     ("simplest", dict(not_nll=True, simplest_siamese=True, pos_victim_lr=0.2, neg_victim_lr=0.3), dict()),
     ("p3n5", dict(), dict(pos_num=3, neg_num=5)),
     ("p4n4", dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), dict(pos_num=4, neg_num=4)),
+    ("retext", dict(not_nll=True, retext=True, pos_victim_lr=0.2, neg_victim_lr=0.2), dict()),
 ])
 def test_attack_variants_match_reference(env, tag, flags, kw):
     path = os.path.join(GOLD, "attack_%s.npz" % tag)

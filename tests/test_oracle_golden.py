@@ -18,7 +18,7 @@ def test_encoder_latents(ae_sd, gold_notnll):
 
 
 @pytest.mark.parametrize("tag,kw", [("notnll", dict(not_nll=True)), ("nll", dict()), ("nll_one", dict(just_use_one=True)),
-                                    ("simplest", dict(not_nll=True, simplest=True)), ("p3n5", dict()), ("p4n4", dict(not_nll=True))])
+                                    ("simplest", dict(not_nll=True, simplest=True)), ("p3n5", dict()), ("p4n4", dict(not_nll=True))])  # (retext goldens: latent jumps on accept, GPU test only)
 def test_scorer_loss_grad_adam(scorer_sd, tag, kw):
     path = os.path.join(GOLD, "attack_%s.npz" % tag)
     if not os.path.exists(path):
