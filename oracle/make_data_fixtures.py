@@ -10,10 +10,11 @@ from safetensors.torch import save_file
 REF = "/root/reference"
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
-os.makedirs(os.path.join(GOLD, "yelp"), exist_ok=True)
-for f in ("neg10_pos10_test0.json", "neg10_pos10_test1.json", "word_to_id.txt"):
-    shutil.copyfile(os.path.join(REF, "data/yelp/processed_files", f), os.path.join(GOLD, "yelp", f))
-    os.chmod(os.path.join(GOLD, "yelp", f), 0o644)
+for task in ("yelp", "amazon"):
+    os.makedirs(os.path.join(GOLD, task), exist_ok=True)
+    for f in ("neg10_pos10_test0.json", "neg10_pos10_test1.json", "word_to_id.txt"):
+        shutil.copyfile(os.path.join(REF, "data/%s/processed_files" % task, f), os.path.join(GOLD, task, f))
+        os.chmod(os.path.join(GOLD, task, f), 0o644)
 for name in ("siamese_model_params", "predictor_net_params"):
     sd = torch.load(os.path.join(REF, "method/yelp/save/origin", name + ".pkl"), map_location="cpu", weights_only=True)
     save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(GOLD, name + ".safetensors"))

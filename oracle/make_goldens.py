@@ -33,7 +33,7 @@ def load_ae(ref_model, args, ckpt):
         if k.endswith(".pe"):
             continue
         src = "src_embed.0.lut.weight" if k == "tgt_embed.0.lut.weight" else k
-        full[k] = sd[src]
+        full[k] = sd[src].float()
     ae.load_state_dict(full)
     ae.eval()
     return ae
@@ -42,7 +42,9 @@ def load_ae(ref_model, args, ckpt):
 def run_attack(subset, flags, ckpt, tag, threads):
     torch.set_num_threads(threads)
     ref_model, ref_data, ref_sc = ref_harness.import_reference()
-    args = ref_harness.make_args("yelp", **flags)
+    flags = dict(flags)
+    task = flags.pop("task", "yelp")
+    args = ref_harness.make_args(task, **flags)   # (amazon ships no Siamese/Predictor: the yelp ones are used)
     ae = load_ae(ref_model, args, ckpt)
     siamese, predictor = ref_sc.SiameseNet(256), ref_sc.Predictor(256)
     ref_sc.load_siamese(siamese, predictor, args)
@@ -225,6 +227,10 @@ if __name__ == "__main__":
     elif a.what == "main":
         subset = list(range(a.n)) + list(range(500, 500 + a.n))
         run_attack(subset, dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "notnll", a.threads)
+    elif a.what == "amazon":
+        ckpt = os.path.join(GOLD, "surrogate_ae_amazon.safetensors")
+        sub = list(range(8)) + list(range(500, 508))
+        run_attack(sub, dict(task="amazon", not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "amazon", a.threads)
     elif a.what == "retext":
         run_attack([0, 1, 2, 3, 500, 501, 502, 503], dict(not_nll=True, retext=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "retext", a.threads)
     elif a.what == "variants":

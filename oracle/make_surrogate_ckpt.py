@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--fp16-round", action="store_true",
+                    help="round the trained weights to fp16-representable values and store them as fp16 (half the "
+                         "file; the checkpoint IS the rounded weights, loaded back as exact f32 by every consumer)")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     ref_model, ref_data, _ = ref_harness.import_reference()
@@ -82,6 +85,8 @@ def main():
             assert torch.equal(v, sd["src_embed.0.lut.weight"])
             continue
         keep[k] = v.detach().clone().contiguous()
+        if a.fp16_round:
+            keep[k] = keep[k].half()
     from safetensors.torch import save_file
     out = a.out or os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "surrogate_ae_%s.safetensors" % a.task)
     save_file(keep, out, metadata={"task": a.task, "steps": str(a.steps), "V": str(V)})

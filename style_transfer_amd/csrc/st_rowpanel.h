@@ -237,25 +237,26 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   }
 }
 
-// number of column splits: enough workgroups for ~2 rounds on 256 CUs x 2 workgroups, at most max_splits,
-// never fewer than one 32-column block per wave; among the admissible counts prefer the one whose
-// per-wave block count is best balanced (a workgroup lasts as long as its busiest wave).
+// number of column splits of a launch: maximise (fill of the last round of 512 resident workgroups) x
+// (balance of 32-column blocks over the waves: a workgroup lasts as long as its busiest wave) x
+// (amortisation of the ~0.25-block panel-load/LayerNorm prologue).
 static inline int rp_splits(int n_rows, int N, int max_splits, int nw = 4) {
-  const int panels = (n_rows + 63) / 64;
+  const int panels = (n_rows + 63) / 64 > 0 ? (n_rows + 63) / 64 : 1;
   const int nblk = (N + 31) / 32;
-  int want = (1024 + panels - 1) / (panels > 0 ? panels : 1);
-  const int cap = (nblk + nw - 1) / nw;
-  if (want > cap) want = cap;
-  if (want > max_splits) want = max_splits;
-  if (want < 1) want = 1;
-  int best = want;
-  double best_eff = 0.0;
-  for (int s = want; s <= max_splits && s <= cap && s <= want * 2; ++s) {
-    const int per = (nblk + s - 1) / s;          // blocks per workgroup
-    const int busiest = (per + nw - 1) / nw;     // blocks of the busiest wave
-    const double eff = (double)nblk / ((double)s * nw * busiest);
-    if (eff > best_eff + 0.02) {
-      best_eff = eff;
+  int cap = (nblk + nw - 1) / nw;
+  if (cap > max_splits) cap = max_splits;
+  int best = 1;
+  double best_score = 0.0;
+  for (int s = 1; s <= cap; ++s) {
+    const int per = (nblk + s - 1) / s;           // blocks per workgroup
+    if ((s - 1) * per >= nblk) continue;          // last split would be empty
+    const int busiest = (per + nw - 1) / nw;      // blocks of the busiest wave
+    const long wgs = (long)panels * s;
+    const long rounds = (wgs + 511) / 512;
+    const double score = ((double)wgs / (rounds * 512.0)) * ((double)nblk / ((double)s * nw * busiest)) *
+                         ((double)busiest / (busiest + 0.25));
+    if (score > best_score * 1.01) {
+      best_score = score;
       best = s;
     }
   }
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
   }
 }
 
-#define RP_FUSE_MIN_ROWS 16384  /* below this the unfused pair (with column splits) fills the chip better */
+#define RP_FUSE_MIN_ROWS 65536  /* below this the unfused pair (with column splits) fills the chip better */
 static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {

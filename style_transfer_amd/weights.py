@@ -35,7 +35,7 @@ def load_state_dict_file(path: str) -> dict:
 
 def expand_ae_state_dict(sd: dict) -> dict:
     """Compact fixture -> full make_model key set (shared embedding under both names, model.py:308-313)."""
-    sd = dict(sd)
+    sd = {k: (v.float() if v.dtype in (torch.float16, torch.bfloat16) else v) for k, v in sd.items()}  # fp16-stored fixtures are exact in f32
     if "tgt_embed.0.lut.weight" not in sd:
         sd["tgt_embed.0.lut.weight"] = sd["src_embed.0.lut.weight"]
     return sd

@@ -282,7 +282,7 @@ def test_errors_are_reported_not_thrown_across_abi(dev, ae):
 
 
 def test_large_batch_paths_equal_small_batch(dev, ae, ae_sd):
-    """Full-size property: above 16384 rows the decoder / encoder switch to the fused O-projection+FFN1
+    """Full-size property: above 65536 rows the decoder / encoder switch to the fused O-projection+FFN1
     kernel and multi-round grids; every replica of a sentence must produce exactly the ids / (nearly) the
     latent of the small-batch run that the oracle checks above."""
     from style_transfer_amd import ops
@@ -291,16 +291,16 @@ def test_large_batch_paths_equal_small_batch(dev, ae, ae_sd):
     t = lambda v: torch.from_numpy(v).to(dev)
     tok, pos, off, mx = pack_sentences(sents)
     lat_small = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx)
-    reps = 60                                             # 2400 sentences, > 16384 token rows
+    reps = 240                                            # 2400 sentences, > 16384 token rows
     tok, pos, off, mx = pack_sentences(sents * reps)
-    assert tok.size >= 16384
+    assert tok.size >= 65536
     lat_big = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents) * reps, mx)
     d = (lat_big.view(reps, len(sents), 256) - lat_small[None]).abs().max().item()
     assert d < 1e-4 * lat_small.abs().max().item(), d
     ids_small, _, _ = ops.greedy_decode(ae, lat_small)
-    big = lat_small.repeat(450, 1).contiguous()           # 18000 decode jobs
+    big = lat_small.repeat(1700, 1).contiguous()          # 68000 decode jobs
     ids_big, _, _ = ops.greedy_decode(ae, big)
-    same = (ids_big.view(450, len(sents), 59) == ids_small[None]).all(dim=2).all(dim=0)
+    same = (ids_big.view(1700, len(sents), 59) == ids_small[None]).all(dim=2).all(dim=0)
     assert int(same.sum().item()) >= len(sents) - 1, same.cpu().tolist()
 
 
