@@ -165,3 +165,30 @@ def test_not_nll_with_unequal_counts_is_rejected_like_the_reference(env):
     r = AttackRunner(env["ae"], env["scorer"], AttackConfig(not_nll=True, log_decodes=False), env["dev"])
     with pytest.raises(ValueError, match="pos_num"):
         r.run_batch(data, [0, 1])
+
+
+def test_attack_amazon_matches_reference(scorer_sd_torch):
+    """BASELINE config 3: amazon test split (origins 9-15 tokens, refs/sims up to 31: the general
+    encoder-attention kernel and decode prefixes beyond 16 keys), V = 19724.  No amazon weights ship, so the
+    golden run used a second surrogate AE (tests/golden/surrogate_ae_amazon.safetensors, fp16-rounded) and the
+    yelp SiameseNet/Predictor."""
+    ck = os.path.join(GOLD, "surrogate_ae_amazon.safetensors")
+    gp = os.path.join(GOLD, "attack_amazon.npz")
+    if not (os.path.exists(ck) and os.path.exists(gp)):
+        pytest.skip("amazon fixtures not generated")
+    from style_transfer_amd import weights as W
+    from style_transfer_amd.data import load_word_dict_info
+    dev = torch.device("cuda", 0)
+    ae = W.AEWeights(W.load_state_dict_file(ck), dev)
+    scorer = W.ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev)
+    id_to_word, V = load_word_dict_info(os.path.join(GOLD, "amazon", "word_to_id.txt"), 5)
+    assert V == 19724 == ae.vocab
+    env = dict(dev=dev, ae=ae, scorer=scorer, V=V, id_to_word=id_to_word,
+               files=[os.path.join(GOLD, "amazon", "neg10_pos10_test%d.json" % i) for i in (0, 1)])
+    g = gold("attack_amazon.npz")
+    data, res = run(env, g, not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2)
+    n_div, report = check_against_golden(res, g)
+    assert n_div == 0, report
+    # encoder latents of all 21 sentences per origin (like/unlike up to 31 tokens)
+    np.testing.assert_allclose(res.trace["like_latent"], g["like_latent"], rtol=0, atol=2e-4 * np.abs(g["like_latent"]).max())
+    np.testing.assert_allclose(res.trace["unlike_latent"], g["unlike_latent"], rtol=0, atol=2e-4 * np.abs(g["unlike_latent"]).max())
