@@ -22,7 +22,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+# MI355X_MICROARCH.md dense MFMA peaks (256 CU x 4 SIMD x 2.4 GHz): v_mfma_f32_32x32x2_f32 = 4096 flop / 64 clk,
+# v_mfma_f32_32x32x16_f16 = 32768 flop / 32 clk
+F32_MFMA_PEAK_TFLOPS = 157.3
+F16_MFMA_PEAK_TFLOPS = 2516.6
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -72,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-decode", type=int, default=9)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--gemm-format", default="f16x3", choices=["f16x3", "f32"],
+                    help="operand format of the AE weight GEMMs: 3-product f16 split (f32-grade results) or exact f32 MFMA")
     a = ap.parse_args()
 
     import torch
@@ -90,7 +95,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors")), dev)
+    ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors")), dev,
+                     gemm_format=a.gemm_format)
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
                              W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
     cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, early_exit=not a.fixed_steps,
@@ -139,11 +145,14 @@ def main():
 
     if rank == 0:
         achieved = gen_fl.value / (gen_ms.value * 1e-3) / 1e12 if gen_ms.value > 0 else 0.0
+        split = a.gemm_format == "f16x3"
+        peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
         out = {
             "metric": "style-transferred sentences/sec, yelp-shape" if a.shape == "yelp" else "style-transferred sentences/sec, amazon-shape",
             "value": world * B * a.steps / dt, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (AE matrix products: f16 hi+lo split operands, 3 products per term, f32 accumulate)" if split else "f32",
+            "data": "synthetic",
             "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d; token ids: %s), %d per GPU per step, flags --attack "
                                    "--not_nll --pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
                                    "surrogate AE checkpoint + shipped Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes off"
@@ -153,11 +162,16 @@ def main():
                        "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
                        "mean_edit_iterations_per_sentence": n_iter_mean,
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
-                       "iters_per_decode": cfg.iters_per_decode,
+                       "iters_per_decode": cfg.iters_per_decode, "gemm_format": a.gemm_format,
                        "edit_iteration_units_per_s": world * units / dt},
-            "roofline": {"bound": "mfma", "kernel": "rp_gemm_kernel<4> = EPI_ARGMAX (generator GEMM + fused argmax)",
-                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+            # achieved = ALGORITHMIC flops (2*rows*256*V per launch) / kernel time.  f16x3 issues 3 MFMA flops per
+            # algorithmic flop, so frac <= 1/3 there by construction; mfma_issue_frac counts the issued ones.
+            "roofline": {"bound": "mfma", "kernel": "rp_gemm_kernel<EPI_ARGMAX,4,%s> (generator GEMM + fused argmax)"
+                                                    % ("true" if split else "false"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "mfma_flops_per_algorithmic_flop": 3 if split else 1,
+                         "mfma_issue_frac": achieved * (3 if split else 1) / peak,
                          "launches": int(gen_n.value), "avg_launch_us": gen_ms.value * 1e3 / max(1, gen_n.value),
                          "kernel_time_share": gen_ms.value * 1e-3 / dt},
         }

@@ -11,8 +11,11 @@
  * stream).  Kernels are launched asynchronously on `stream`; only st_decode_greedy synchronises it
  * (to read back the live-sentence count, see below).
  *
- * Arithmetic type everywhere: IEEE f32 (the reference's dtype), matrix products on the f32-input
- * MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain).  Token ids are int32.
+ * Arithmetic type everywhere: IEEE f32 (the reference's dtype) in memory and in every non-matrix
+ * operation.  Matrix products against packed weights run in one of two operand formats, chosen when
+ * the weights are packed (ST_GEMM_*, below): exact f32 on v_mfma_f32_32x32x2_f32 (bit-identical to an
+ * fmaf chain), or the 3-product f16 split on v_mfma_f32_32x32x16_f16 (f32 accumulate, ~2^-22 relative
+ * error per term).  The style scorer and the in-batch loss always use the exact form.  Token ids are int32.
  */
 #ifndef ST_KERNELS_H
 #define ST_KERNELS_H
@@ -46,12 +49,19 @@ int st_profile_enable(int on);
 int st_profile_read(double* gen_ms, double* gen_flops, long long* gen_launches, int reset);
 
 /* Weight packing (no reference counterpart).  The GEMM kernels read nn.Linear weight matrices
- * W [N,K] row-major in MFMA-fragment order so that every wave load is one coalesced 1 KiB read:
- *   packed[((blk*(K/8) + kg)*64 + lane)*4 + j] = W[blk*32 + (lane&31)][kg*8 + 4*(lane>>5) + j]
- * (rows >= N are zero).  Fields documented as "packed" below must point at such an image; pack once
- * at load time.  st_packed_weight_floats gives the image size in floats.                         */
+ * W [N,K] row-major in MFMA-fragment order so that every wave load is one coalesced 1 KiB read.
+ *   ST_GEMM_F32   : packed[((blk*(K/8) + kg)*64 + lane)*4 + j] = W[blk*32 + (lane&31)][kg*8 + 4*(lane>>5) + j]
+ *   ST_GEMM_F16X3 : W = hi + lo with hi = f16(W), lo = f16(W - hi); 16-byte fragments of 8 halves,
+ *                   fragment[((blk*(K/16) + step)*2 + part)*64 + lane][j] = part(W[blk*32 + (lane&31)][16*step + 8*(lane>>5) + j]),
+ *                   part 0 = hi, 1 = lo.  Requires |W| < 65504 (f16 range); so must the activations it
+ *                   multiplies (LayerNorm outputs, attention outputs, ReLU hidden units).
+ * (rows >= N are zero).  Both images take st_packed_weight_floats(N, K) floats.  Fields documented as
+ * "packed" below must point at such an image; a weights struct's `gemm_format` says which one ALL of
+ * its packed fields use.  K % 16 == 0.                                                           */
+#define ST_GEMM_F32 0
+#define ST_GEMM_F16X3 1
 size_t st_packed_weight_floats(int N, int K);
-int st_pack_weight(const float* W, int N, int K, float* out_packed, void* stream);
+int st_pack_weight(const float* W, int N, int K, int gemm_format, float* out_packed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (1) Style scorer: SiameseNet + Predictor + contrastive score + backward-to-latent + Adam.
@@ -111,6 +121,7 @@ typedef struct StDecLayer {
 
 typedef struct StDecoderWeights {
   int32_t d_model, n_heads, d_ff, n_layers, vocab, pe_rows;
+  int32_t gemm_format, reserved0;      /* ST_GEMM_*: format of every PACKED field below          */
   const float* emb;                    /* tgt_embed.0.lut.weight [V,256]                        */
   const float* pe;                     /* tgt_embed.1.pe [pe_rows,256]                          */
   const float *lnf_a, *lnf_b;          /* decoder.norm                                          */
@@ -140,10 +151,11 @@ int st_decode_greedy(const StDecoderWeights* w, const float* latent, int B, int 
 /* ---------------------------------------------------------------------------------------------
  * (3) Generator GEMM + argmax: ids[r] = argmax_v( LN(h[r]) . W[v] + b[v] )  (model.py:200-207 +
  * torch.max(prob, dim=1), :290-292; log_softmax is argmax-invariant and skipped; ties -> lowest
- * index).  W is PACKED (st_pack_weight).  ln_a/ln_b may be NULL.  scratch: n*ST_ARGMAX_SPLITS*16 bytes. */
+ * index).  W is PACKED (st_pack_weight) in `gemm_format`.  ln_a/ln_b may be NULL.
+ * scratch: n*ST_ARGMAX_SPLITS*16 bytes. */
 #define ST_ARGMAX_SPLITS 4
 int st_gemm_argmax(const float* h, const float* ln_a, const float* ln_b, const float* W,
-                   const float* b, int n, int V, int32_t* ids, float* best, float* gap,
+                   const float* b, int n, int V, int gemm_format, int32_t* ids, float* best, float* gap,
                    void* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -185,6 +197,7 @@ typedef struct StEncLayer {
 } StEncLayer;
 typedef struct StEncoderWeights {
   int32_t d_model, n_heads, d_ff, n_layers, vocab, pe_rows;
+  int32_t gemm_format, reserved0;      /* ST_GEMM_*: format of wqkv / wo / w1 / w2 (all PACKED)  */
   const float* emb;                    /* src_embed.0.lut.weight [V,256] (shared with tgt)      */
   const float* pe;                     /* src_embed.1.pe                                        */
   const float *lnf_a, *lnf_b;          /* encoder.norm                                          */

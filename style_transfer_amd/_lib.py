@@ -11,6 +11,9 @@ ST_MAX_REFS = 16
 ST_ARGMAX_SPLITS = 4
 ST_F_NOT_NLL, ST_F_SIMPLEST, ST_F_JUST_USE_ONE = 1, 2, 4
 ST_DEC_EARLY_EXIT = 1
+ST_GEMM_F32, ST_GEMM_F16X3 = 0, 1
+GEMM_FORMATS = {"f32": ST_GEMM_F32, "f16x3": ST_GEMM_F16X3}
+ABI_VERSION = 2
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -30,6 +33,7 @@ class StDecLayer(C.Structure):
 class StDecoderWeights(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
                 ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
+                ("gemm_format", C.c_int32), ("reserved0", C.c_int32),
                 ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp), ("gen_w", fp), ("gen_b", fp),
                 ("layer", StDecLayer * ST_MAX_LAYERS)]
 
@@ -42,6 +46,7 @@ class StEncLayer(C.Structure):
 class StEncoderWeights(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
                 ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
+                ("gemm_format", C.c_int32), ("reserved0", C.c_int32),
                 ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp),
                 ("layer", StEncLayer * ST_MAX_LAYERS)]
 
@@ -53,14 +58,14 @@ EXPORTS = {
     "st_profile_enable": (C.c_int, [C.c_int]),
     "st_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "st_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
-    "st_pack_weight": (C.c_int, [fp, C.c_int, C.c_int, fp, fp]),
+    "st_pack_weight": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp]),
     "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
     "st_scorer_edit_step": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                       C.c_int, C.c_float, C.c_int, fp, fp, fp]),
     "st_decode_workspace_bytes": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int, C.c_int]),
     "st_decode_greedy": (C.c_int, [C.POINTER(StDecoderWeights), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, fp, fp, fp, C.c_size_t, C.POINTER(C.c_int), fp]),
-    "st_gemm_argmax": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp]),
+    "st_gemm_argmax": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp]),
     "st_accept_changes": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp,
                                     fp, fp, fp, fp, fp]),
     "st_simloss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),

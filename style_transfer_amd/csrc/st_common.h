@@ -9,6 +9,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 void st_set_error(const char* fmt, ...);
 
@@ -49,3 +51,21 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// ---- f16x3 split products (gemm_format ST_GEMM_F16X3) -------------------------------------------
+// x = hi + lo + O(2^-22 |x|) with hi = f16(x), lo = f16(x - hi)  (f16 subnormals are kept by the
+// conversion and by the MFMA on gfx950, so the absolute residual is <= 2^-25 for small x);
+// x.w ~ hi.whi + hi.wlo + lo.whi on v_mfma_f32_32x32x16_f16 (products exact, f32 accumulate).
+__device__ __forceinline__ void split_f16(f32x4 v, h4& hi, h4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const _Float16 h = (_Float16)v[j];
+    hi[j] = h;
+    lo[j] = (_Float16)(v[j] - (float)h);
+  }
+}
+// D += A(32x16) * B(16x32): lane (r = lane&31, h = lane>>5) holds A[r][8h..8h+7], B[8h..8h+7][r]
+__device__ __forceinline__ f32x16 mfma16h(h8 a, h8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ h8 as_h8(f32x4 v) { return __builtin_bit_cast(h8, v); }

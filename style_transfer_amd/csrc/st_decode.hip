@@ -15,7 +15,7 @@ void st_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 1; }
+extern "C" int st_abi_version(void) { return 2; }
 
 // ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
 #include <vector>
@@ -287,6 +287,7 @@ static int check_weights(const StDecoderWeights* w, int max_len) {
   ST_CHECK_ARG(w->d_ff > 0 && w->d_ff % 256 == 0, "d_ff=%d must be a positive multiple of 256", w->d_ff);
   ST_CHECK_ARG(w->n_layers >= 1 && w->n_layers <= ST_MAX_LAYERS, "n_layers=%d out of range", w->n_layers);
   ST_CHECK_ARG(w->vocab >= 4, "vocab=%d too small", w->vocab);
+  ST_CHECK_ARG(w->gemm_format == ST_GEMM_F32 || w->gemm_format == ST_GEMM_F16X3, "gemm_format=%d unknown", w->gemm_format);
   ST_CHECK_ARG(max_len >= 2 && max_len - 1 <= 64, "max_len=%d unsupported (decode length max_len-1 must be <= 64)", max_len);
   ST_CHECK_ARG(w->pe_rows >= max_len - 1, "pe_rows=%d < decode length %d", w->pe_rows, max_len - 1);
   ST_CHECK_ARG(w->emb && w->pe && w->lnf_a && w->lnf_b && w->gen_w && w->gen_b, "NULL weight pointer");
@@ -331,6 +332,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   // cross-attention constants: cc[l] = (latent Wv^T + bv) Wo^T + bo   (one key => softmax == 1)
   for (int l = 0; l < L; ++l) {
     GemmArgs g = {};
+    g.fmt = w->gemm_format;
     g.X = latent; g.n_host = B; g.W = w->layer[l].xv_w; g.bias = w->layer[l].xv_b; g.N = 256;
     g.out = ws.att; g.ldo = 256;
     ST_TRY(launch_rp<EPI_BIAS>(g, B, 1, st));
@@ -354,6 +356,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       float* kb = ws.kv + (size_t)(l * 2 + 0) * T * 256;
       float* vb = ws.kv + (size_t)(l * 2 + 1) * T * 256;
       GemmArgs g = {};
+      g.fmt = w->gemm_format;
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
@@ -367,26 +370,31 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       ST_LAUNCH_CHECK();
       if (n_bound >= RP_FUSE_MIN_ROWS) {
         OFArgs of = {};
+        of.fmt = w->gemm_format;
         of.att = ws.att; of.n_dev = n_dev; of.n_host = n_bound; of.wo = y.wo; of.bo = y.bo; of.x = ws.x;
         of.cconst = ws.cc + (size_t)l * B * 256; of.idx = idx; of.ln_a = y.ln2_a; of.ln_b = y.ln2_b;
         of.w1 = y.w1; of.b1 = y.b1; of.h = ws.h; of.d_ff = w->d_ff;
         ST_TRY(launch_oproj_ffn1(of, n_bound, st));
       } else {
         GemmArgs o = {};
+        o.fmt = w->gemm_format;
         o.X = ws.att; o.n_dev = n_dev; o.n_host = n_bound; o.W = y.wo; o.bias = y.bo; o.N = 256;
         o.out = ws.x; o.ldo = 256; o.resid = ws.x; o.cconst = ws.cc + (size_t)l * B * 256; o.ld_cc = 256; o.idx = idx;
         ST_TRY(launch_rp<EPI_RESID>(o, n_bound, rp_splits(n_bound, 256, 2), st));
         GemmArgs f1 = {};
+        f1.fmt = w->gemm_format;
         f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
         f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
         ST_TRY((launch_rp<EPI_RELU, 8>(f1, n_bound, rp_splits(n_bound, w->d_ff, 4, 8), st)));
       }
       GemmArgs f2 = {};
+      f2.fmt = w->gemm_format;
       f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
       f2.out = ws.x; f2.ldo = 256; f2.resid = ws.x;
       ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, n_bound, st));
     }
     GemmArgs gg = {};
+    gg.fmt = w->gemm_format;
     gg.X = ws.x; gg.n_dev = n_dev; gg.n_host = n_bound; gg.ln_a = w->lnf_a; gg.ln_b = w->lnf_b;
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
     ProfPair pp;
@@ -414,13 +422,16 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
 }
 
 extern "C" int st_gemm_argmax(const float* h, const float* ln_a, const float* ln_b, const float* W, const float* b,
-                              int n, int V, int32_t* ids, float* best, float* gap, void* scratch, void* stream) {
+                              int n, int V, int gemm_format, int32_t* ids, float* best, float* gap, void* scratch,
+                              void* stream) {
   ST_CHECK_ARG(n >= 0 && V >= 1, "n=%d V=%d", n, V);
+  ST_CHECK_ARG(gemm_format == ST_GEMM_F32 || gemm_format == ST_GEMM_F16X3, "gemm_format=%d unknown", gemm_format);
   if (n == 0) return ST_OK;
   ST_CHECK_ARG(h && W && b && ids && scratch, "NULL buffer");
   ST_CHECK_ARG((ln_a == nullptr) == (ln_b == nullptr), "ln_a and ln_b must both be given or both NULL");
   hipStream_t st = (hipStream_t)stream;
   GemmArgs gg = {};
+  gg.fmt = gemm_format;
   gg.X = h; gg.n_host = n; gg.ln_a = ln_a; gg.ln_b = ln_b; gg.W = W; gg.bias = b; gg.N = V;
   gg.partial = (float4*)scratch;
   ST_TRY(launch_rp<EPI_ARGMAX>(gg, n, ST_ARGMAX_SPLITS, st));
@@ -432,11 +443,20 @@ extern "C" int st_gemm_argmax(const float* h, const float* ln_a, const float* ln
 
 extern "C" size_t st_packed_weight_floats(int N, int K) { return (N > 0 && K > 0 && K % 8 == 0) ? rp_packed_floats(N, K) : 0; }
 
-extern "C" int st_pack_weight(const float* W, int N, int K, float* out, void* stream) {
+extern "C" int st_pack_weight(const float* W, int N, int K, int gemm_format, float* out, void* stream) {
   ST_CHECK_ARG(W && out, "NULL buffer");
-  ST_CHECK_ARG(N > 0 && K > 0 && K % 8 == 0, "N=%d K=%d (K must be a positive multiple of 8)", N, K);
-  const size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
-  hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, N, K, out);
+  if (gemm_format == ST_GEMM_F16X3) {
+    ST_CHECK_ARG(N > 0 && K > 0 && K % 16 == 0, "N=%d K=%d (K must be a positive multiple of 16)", N, K);
+    const size_t total = (size_t)((N + 31) / 32) * (K >> 4) * 64;
+    hipLaunchKernelGGL(pack_weight_h_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, N, K,
+                       out);
+  } else {
+    ST_CHECK_ARG(gemm_format == ST_GEMM_F32, "gemm_format=%d unknown", gemm_format);
+    ST_CHECK_ARG(N > 0 && K > 0 && K % 8 == 0, "N=%d K=%d (K must be a positive multiple of 8)", N, K);
+    const size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
+    hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, N, K,
+                       out);
+  }
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

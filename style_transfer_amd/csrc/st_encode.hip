@@ -152,6 +152,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     return ST_OK;
   }
   ST_CHECK_ARG(tokens && tok_pos && workspace, "NULL buffer");
+  ST_CHECK_ARG(w->gemm_format == ST_GEMM_F32 || w->gemm_format == ST_GEMM_F16X3, "gemm_format=%d unknown", w->gemm_format);
   const size_t need = st_encode_workspace_bytes(w, n_rows, n_sent);
   if (need > workspace_bytes) {
     st_set_error("encode workspace too small: need %zu bytes, have %zu", need, workspace_bytes);
@@ -170,6 +171,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     ST_CHECK_ARG(y.ln0_a && y.ln0_b && y.wqkv && y.bqkv && y.wo && y.bo && y.ln1_a && y.ln1_b && y.w1 && y.b1 && y.w2 && y.b2,
                  "NULL weight pointer in encoder layer %d", l);
     GemmArgs g = {};
+    g.fmt = w->gemm_format;
     g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
     g.out = qkv; g.ldo = 768;
     ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, rp_splits(R, 768, 3, 8), st)));
@@ -178,19 +180,23 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     ST_LAUNCH_CHECK();
     if (R >= RP_FUSE_MIN_ROWS) {
       OFArgs of = {};
+      of.fmt = w->gemm_format;
       of.att = att; of.n_host = R; of.wo = y.wo; of.bo = y.bo; of.x = x; of.ln_a = y.ln1_a; of.ln_b = y.ln1_b;
       of.w1 = y.w1; of.b1 = y.b1; of.h = h; of.d_ff = w->d_ff;
       ST_TRY(launch_oproj_ffn1(of, R, st));
     } else {
       GemmArgs o = {};
+      o.fmt = w->gemm_format;
       o.X = att; o.n_host = R; o.W = y.wo; o.bias = y.bo; o.N = 256; o.out = x; o.ldo = 256; o.resid = x;
       ST_TRY(launch_rp<EPI_RESID>(o, R, rp_splits(R, 256, 2), st));
       GemmArgs f1 = {};
+      f1.fmt = w->gemm_format;
       f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
       f1.out = h; f1.ldo = w->d_ff;
       ST_TRY((launch_rp<EPI_RELU, 8>(f1, R, rp_splits(R, w->d_ff, 4, 8), st)));
     }
     GemmArgs f2 = {};
+    f2.fmt = w->gemm_format;
     f2.X = h; f2.n_host = R; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256; f2.out = x; f2.ldo = 256; f2.resid = x;
     ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, R, st));
   }

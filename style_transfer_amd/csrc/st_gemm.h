@@ -50,6 +50,7 @@ struct GemmArgs {
   int row_offset;
   const float* lse;
   const float* g;
+  int fmt;             // row-panel kernels: operand format of the packed W (ST_GEMM_F32 / ST_GEMM_F16X3)
 };
 
 struct Lse {

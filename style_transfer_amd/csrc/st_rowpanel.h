@@ -9,6 +9,14 @@
 // is one fully coalesced 1 KiB read:
 //     packed[((blk*(K/8) + kg)*64 + lane)*4 + j] = W[blk*32 + (lane&31)][kg*8 + 4*(lane>>5) + j]
 // (the lane<->k permutation of st_gemm.h).  A fragments come from the LDS panel (conflict-free b128).
+//
+// H = true (gemm_format ST_GEMM_F16X3): the same kernels on v_mfma_f32_32x32x16_f16 with both operands
+// split into f16 hi + lo parts and three products per step (hi.hi + hi.lo + lo.hi, st_common.h):
+// f32-grade results (~2^-22 relative per term) at up to 16/3 of the f32 MFMA rate.  The LDS panel row
+// keeps its 260-dword stride: dwords [0,128) hold the 256 hi halves, [128,256) the lo halves, so the
+// b128 fragment reads (8 consecutive k per lane) have the bank pattern of the f32 layout.  Packed W:
+//     [block][step = k/16][hi|lo][lane][8 halves],  half j of lane = W[blk*32 + (lane&31)][16*step + 8*(lane>>5) + j]
+// (same size in bytes as the f32 image).
 #pragma once
 #include "st_gemm.h"
 
@@ -22,7 +30,21 @@
 
 #define RP_LDS ((64 * ST_LDA + 8 * 64 * 4) * 4)
 
-template <int EPI, int NW = 4>
+// store 4 consecutive features of a panel row (feature index c = 4*c4) in the kernel's operand format
+template <bool H>
+__device__ __forceinline__ void panel_store4(float* row, int c4, f32x4 v) {
+  if (H) {
+    h4 hi, lo;
+    split_f16(v, hi, lo);
+    _Float16* ph = (_Float16*)row;
+    *(h4*)(ph + c4 * 4) = hi;
+    *(h4*)(ph + 256 + c4 * 4) = lo;
+  } else {
+    *(f32x4*)(row + c4 * 4) = v;
+  }
+}
+
+template <int EPI, int NW = 4, bool H = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;                  // [64][ST_LDA]
@@ -34,23 +56,30 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
 
   // ---- X panel -> LDS (64 rows x 64 float4, 16 per thread), optional LayerNorm ----
-#pragma unroll
-  for (int i = 0; i < 64 / NW; ++i) {
-    const int f = tid + i * 64 * NW;
-    const int r = f >> 6, c4 = f & 63;
-    *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
-  }
-  __syncthreads();
   if (a.ln_a) {
+#pragma unroll
+    for (int i = 0; i < 64 / NW; ++i) {
+      const int f = tid + i * 64 * NW;
+      const int r = f >> 6, c4 = f & 63;
+      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+    }
+    __syncthreads();
     const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
     const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
 #pragma unroll 4
     for (int rr = 0; rr < 64 / NW; ++rr) {
-      float* p = As + (wave * (64 / NW) + rr) * ST_LDA + lane * 4;
-      *(f32x4*)p = layernorm256(*(f32x4*)p, ga, gb);
+      float* row = As + (wave * (64 / NW) + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
+      panel_store4<H>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
     }
-    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64 / NW; ++i) {
+      const int f = tid + i * 64 * NW;
+      const int r = f >> 6, c4 = f & 63;
+      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
+    }
   }
+  __syncthreads();
 
   Top2 best[2][16];
   Lse run[2][16];
@@ -72,29 +101,35 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
     }
 
   // this workgroup's column blocks [b0, b1), this wave's: b0 + wave + NW*i
+  constexpr int SPB = H ? 16 : 32;              // ring steps per 32-column block (K = 256)
+  constexpr int R = H ? (NW == 8 ? 4 : 8) : 8;  // ring depth in steps
   const int nblk = (a.N + 31) >> 5;
   const int per = (nblk + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per;
   const int b1 = min(nblk, b0 + per);
   const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + NW - 1) / NW : 0;
-  const int total = cnt * 32;  // (block, kg) steps
-  const float* Wl = a.W + (size_t)lane * 4;
-  auto wload = [&](int g) -> f32x4 {
+  const int total = cnt * SPB;  // (block, k-step) steps
+  const f32x4* Wl = (const f32x4*)a.W + lane;
+  // f32: one 1 KiB fragment per step; f16x3: a hi and a lo fragment (p = 0, 1)
+  auto wload = [&](int g, int p) -> f32x4 {
     g = min(g, total - 1);
-    const int blk = b0 + wave + NW * (g >> 5);
-    return *(const f32x4*)(Wl + ((size_t)blk * 32 + (g & 31)) * 256);
+    const int blk = b0 + wave + NW * (g / SPB);
+    return H ? Wl[(((size_t)blk * SPB + (g & (SPB - 1))) * 2 + p) * 64] : Wl[((size_t)blk * SPB + (g & (SPB - 1))) * 64];
   };
-  f32x4 ring[8];
+  f32x4 ring[R], ringl[H ? R : 1];
   if (total > 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ring[j] = wload(j);
+    for (int j = 0; j < R; ++j) {
+      ring[j] = wload(j, 0);
+      if (H) ringl[j] = wload(j, 1);
+    }
   }
   const float* Ab = As + l31 * ST_LDA + 4 * half;
   f32x16 acc0 = {0}, acc1 = {0};
   float pre[2][16];  // RESID: residual (+ cross-attention constant), fetched while the block's MFMAs run
-  for (int g0 = 0; g0 < total; g0 += 8) {
-    if (EPI == EPI_RESID && (g0 & 31) == 0) {
-      const int col = min(((b0 + wave + NW * (g0 >> 5)) << 5) + l31, a.N - 1);
+  for (int g0 = 0; g0 < total; g0 += R) {
+    if (EPI == EPI_RESID && (g0 & (SPB - 1)) == 0) {
+      const int col = min(((b0 + wave + NW * (g0 / SPB)) << 5) + l31, a.N - 1);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -106,21 +141,36 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kg = (g0 + j) & 31;
-      const f32x4 b = ring[j];
-      ring[j] = wload(g0 + j + 8);
-      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
-      const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+    for (int j = 0; j < R; ++j) {
+      const int kg = (g0 + j) & (SPB - 1);
+      if (H) {
+        const h8 bh = as_h8(ring[j]), bl = as_h8(ringl[j]);
+        ring[j] = wload(g0 + j + R, 0);
+        ringl[j] = wload(g0 + j + R, 1);
+        const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
+        const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
+        const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
+        acc0 = mfma16h(a0h, bh, acc0);
+        acc1 = mfma16h(a1h, bh, acc1);
+        acc0 = mfma16h(a0h, bl, acc0);
+        acc1 = mfma16h(a1h, bl, acc1);
+        acc0 = mfma16h(a0l, bh, acc0);
+        acc1 = mfma16h(a1l, bh, acc1);
+      } else {
+        const f32x4 b = ring[j];
+        ring[j] = wload(g0 + j + R, 0);
+        const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+        const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc0 = mfma32(a0[s], b[s], acc0);
-        acc1 = mfma32(a1[s], b[s], acc1);
+        for (int s = 0; s < 4; ++s) {
+          acc0 = mfma32(a0[s], b[s], acc0);
+          acc1 = mfma32(a1[s], b[s], acc1);
+        }
       }
     }
-    if (((g0 + 8) & 31) == 0) {
+    if (((g0 + R) & (SPB - 1)) == 0) {
       // ---- epilogue for this wave's column block ----
-      const int col = ((b0 + wave + NW * (g0 >> 5)) << 5) + l31;
+      const int col = ((b0 + wave + NW * (g0 / SPB)) << 5) + l31;
       const bool colok = col < a.N;
       const float bv = (colok && a.bias) ? a.bias[col] : 0.0f;
 #pragma unroll
@@ -263,18 +313,24 @@ static inline int rp_splits(int n_rows, int N, int max_splits, int nw = 4) {
   return best;
 }
 
-template <int EPI, int NW = 4>
-static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+template <int EPI, int NW, bool H>
+static int launch_rp_t(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
+    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI, NW, H>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
     attr_done = true;
   }
   if (n_bound <= 0) return ST_OK;
   dim3 grid((n_bound + 63) / 64, splits);
-  hipLaunchKernelGGL((rp_gemm_kernel<EPI, NW>), grid, dim3(64 * NW), RP_LDS, st, a);
+  hipLaunchKernelGGL((rp_gemm_kernel<EPI, NW, H>), grid, dim3(64 * NW), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
+}
+// a.fmt selects the operand format the packed W image was built for (ST_GEMM_F32 / ST_GEMM_F16X3)
+template <int EPI, int NW = 4>
+static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+  return a.fmt == ST_GEMM_F16X3 ? launch_rp_t<EPI, NW, true>(a, n_bound, splits, st)
+                                : launch_rp_t<EPI, NW, false>(a, n_bound, splits, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,7 +338,7 @@ static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st)
 // (reloaded into LDS between two barriers), the whole [64,256] output stays in accumulators
 // (wave w owns column blocks w and w+4: 2 blocks x 2 row tiles = 64 registers).  Epilogue: BIAS/RESID.
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool H = false>
 __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;
@@ -291,20 +347,27 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
   if (m0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int K = a.K, kgs = K >> 3, nchunk = K >> 8;
+  constexpr int SPC = H ? 16 : 32;  // ring steps per 256-wide K chunk
+  constexpr int F = H ? 2 : 1;      // fragments per step
+  const int K = a.K, nchunk = K >> 8, spb = nchunk * SPC;  // steps per column block
   // split-K (gridDim.y > 1): this workgroup sums chunks [c_begin, c_end) into slab blockIdx.y of `out`
   // ([gridDim.y][n_host][ldo]; summed by slab_reduce_kernel); the caller passes bias == resid == null
   const int cps = (nchunk + gridDim.y - 1) / gridDim.y;
   const int c_begin = blockIdx.y * cps, c_end = min(nchunk, c_begin + cps);
   float* outp = a.out + (size_t)blockIdx.y * a.n_host * a.ldo;
-  const float* W0 = a.W + ((size_t)wave * kgs) * 256 + (size_t)lane * 4;        // block `wave`
-  const float* W1 = a.W + ((size_t)(wave + 4) * kgs) * 256 + (size_t)lane * 4;  // block `wave + 4`
-  const int total = max(c_end * 32, 1);
-  f32x4 r0[4], r1[4];
+  const f32x4* W0 = (const f32x4*)a.W + (size_t)wave * spb * F * 64 + lane;        // block `wave`
+  const f32x4* W1 = (const f32x4*)a.W + (size_t)(wave + 4) * spb * F * 64 + lane;  // block `wave + 4`
+  const int total = max(c_end * SPC, 1);
+  f32x4 r0[4], r1[4], r0l[H ? 4 : 1], r1l[H ? 4 : 1];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    r0[j] = *(const f32x4*)(W0 + (size_t)min(c_begin * 32 + j, total - 1) * 256);
-    r1[j] = *(const f32x4*)(W1 + (size_t)min(c_begin * 32 + j, total - 1) * 256);
+    const size_t o = (size_t)min(c_begin * SPC + j, total - 1) * F * 64;
+    r0[j] = W0[o];
+    r1[j] = W1[o];
+    if (H) {
+      r0l[j] = W0[o + 64];
+      r1l[j] = W1[o + 64];
+    }
   }
   // accumulators start from bias (+ residual + cross constant): the fetch overlaps the whole K loop
   f32x16 acc[2][2];
@@ -332,25 +395,48 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
     for (int i = 0; i < 16; ++i) {
       const int f = tid + i * 256;
       const int r = f >> 6, c4 = f & 63;
-      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * K + c * 256 + c4 * 4);
+      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * K + c * 256 + c4 * 4));
     }
     __syncthreads();
-    for (int g0 = 0; g0 < 32; g0 += 4) {
+    for (int g0 = 0; g0 < SPC; g0 += 4) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kg = g0 + j;
-        const f32x4 b0 = r0[j], b1 = r1[j];
-        const int nx = min(c * 32 + kg + 4, total - 1);
-        r0[j] = *(const f32x4*)(W0 + (size_t)nx * 256);
-        r1[j] = *(const f32x4*)(W1 + (size_t)nx * 256);
-        const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
-        const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+        const size_t nx = (size_t)min(c * SPC + kg + 4, total - 1) * F * 64;
+        if (H) {
+          const h8 b0h = as_h8(r0[j]), b1h = as_h8(r1[j]), b0l = as_h8(r0l[j]), b1l = as_h8(r1l[j]);
+          r0[j] = W0[nx];
+          r1[j] = W1[nx];
+          r0l[j] = W0[nx + 64];
+          r1l[j] = W1[nx + 64];
+          const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
+          const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
+          const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
+          acc[0][0] = mfma16h(a0h, b0h, acc[0][0]);
+          acc[1][0] = mfma16h(a1h, b0h, acc[1][0]);
+          acc[0][1] = mfma16h(a0h, b1h, acc[0][1]);
+          acc[1][1] = mfma16h(a1h, b1h, acc[1][1]);
+          acc[0][0] = mfma16h(a0h, b0l, acc[0][0]);
+          acc[1][0] = mfma16h(a1h, b0l, acc[1][0]);
+          acc[0][1] = mfma16h(a0h, b1l, acc[0][1]);
+          acc[1][1] = mfma16h(a1h, b1l, acc[1][1]);
+          acc[0][0] = mfma16h(a0l, b0h, acc[0][0]);
+          acc[1][0] = mfma16h(a1l, b0h, acc[1][0]);
+          acc[0][1] = mfma16h(a0l, b1h, acc[0][1]);
+          acc[1][1] = mfma16h(a1l, b1h, acc[1][1]);
+        } else {
+          const f32x4 b0 = r0[j], b1 = r1[j];
+          r0[j] = W0[nx];
+          r1[j] = W1[nx];
+          const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+          const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
-          acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
-          acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
-          acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+          for (int s = 0; s < 4; ++s) {
+            acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
+            acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
+            acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
+            acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+          }
         }
       }
     }
@@ -379,11 +465,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   *(f32x4*)(out + i * 4) = s;
 }
 
-template <int EPI>
-static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st, int ksplit = 1) {
+template <int EPI, bool H>
+static int launch_rp_kchunk_t(const GemmArgs& a, int n_bound, hipStream_t st, int ksplit) {
   static bool attr_done = false;
   if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_kchunk_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
+    ST_HIP(hipFuncSetAttribute((const void*)rp_kchunk_kernel<EPI, H>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
     attr_done = true;
   }
   if (n_bound <= 0) return ST_OK;
@@ -391,9 +477,14 @@ static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st, int 
     st_set_error("rp_kchunk: needs N == 256 and K a multiple of 256 (N=%d K=%d)", a.N, a.K);
     return ST_EINVAL;
   }
-  hipLaunchKernelGGL(rp_kchunk_kernel<EPI>, dim3((n_bound + 63) / 64, ksplit), dim3(256), RP_LDS, st, a);
+  hipLaunchKernelGGL((rp_kchunk_kernel<EPI, H>), dim3((n_bound + 63) / 64, ksplit), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
+}
+template <int EPI>
+static int launch_rp_kchunk(const GemmArgs& a, int n_bound, hipStream_t st, int ksplit = 1) {
+  return a.fmt == ST_GEMM_F16X3 ? launch_rp_kchunk_t<EPI, true>(a, n_bound, st, ksplit)
+                                : launch_rp_kchunk_t<EPI, false>(a, n_bound, st, ksplit);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -415,9 +506,10 @@ struct OFArgs {
   const float *w1, *b1;          // packed [d_ff,256], [d_ff]
   float* h;                      // [n,d_ff]
   int d_ff;
+  int fmt;                       // operand format of wo / w1 (ST_GEMM_F32 / ST_GEMM_F16X3)
 };
 
-template <int UNUSED = 0>
+template <bool H = false>
 __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;
@@ -426,20 +518,26 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
   if (m0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
+  constexpr int SPB = H ? 16 : 32;  // ring steps per 32-column block (K = 256)
+  constexpr int F = H ? 2 : 1;      // fragments per step
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int f = tid + i * 256;
     const int r = f >> 6, c4 = f & 63;
-    *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+    panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
   }
   // ---- phase 1: O-projection, accumulators start from bias + residual (+ constant) ----
-  const float* W0 = a.wo + ((size_t)wave * 32) * 256 + (size_t)lane * 4;
-  const float* W1 = a.wo + ((size_t)(wave + 4) * 32) * 256 + (size_t)lane * 4;
-  f32x4 r0[4], r1[4];
+  const f32x4* W0 = (const f32x4*)a.wo + (size_t)wave * SPB * F * 64 + lane;
+  const f32x4* W1 = (const f32x4*)a.wo + (size_t)(wave + 4) * SPB * F * 64 + lane;
+  f32x4 r0[4], r1[4], r0l[H ? 4 : 1], r1l[H ? 4 : 1];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    r0[j] = *(const f32x4*)(W0 + (size_t)j * 256);
-    r1[j] = *(const f32x4*)(W1 + (size_t)j * 256);
+    r0[j] = W0[(size_t)j * F * 64];
+    r1[j] = W1[(size_t)j * F * 64];
+    if (H) {
+      r0l[j] = W0[(size_t)j * F * 64 + 64];
+      r1l[j] = W1[(size_t)j * F * 64 + 64];
+    }
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -458,22 +556,45 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
   }
   __syncthreads();
   const float* Ab = As + l31 * ST_LDA + 4 * half;
-  for (int g0 = 0; g0 < 32; g0 += 4) {
+  for (int g0 = 0; g0 < SPB; g0 += 4) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int kg = g0 + j;
-      const f32x4 b0 = r0[j], b1 = r1[j];
-      const int nx = min(kg + 4, 31);
-      r0[j] = *(const f32x4*)(W0 + (size_t)nx * 256);
-      r1[j] = *(const f32x4*)(W1 + (size_t)nx * 256);
-      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
-      const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+      const size_t nx = (size_t)min(kg + 4, SPB - 1) * F * 64;
+      if (H) {
+        const h8 b0h = as_h8(r0[j]), b1h = as_h8(r1[j]), b0l = as_h8(r0l[j]), b1l = as_h8(r1l[j]);
+        r0[j] = W0[nx];
+        r1[j] = W1[nx];
+        r0l[j] = W0[nx + 64];
+        r1l[j] = W1[nx + 64];
+        const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
+        const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
+        const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
+        acc[0][0] = mfma16h(a0h, b0h, acc[0][0]);
+        acc[1][0] = mfma16h(a1h, b0h, acc[1][0]);
+        acc[0][1] = mfma16h(a0h, b1h, acc[0][1]);
+        acc[1][1] = mfma16h(a1h, b1h, acc[1][1]);
+        acc[0][0] = mfma16h(a0h, b0l, acc[0][0]);
+        acc[1][0] = mfma16h(a1h, b0l, acc[1][0]);
+        acc[0][1] = mfma16h(a0h, b1l, acc[0][1]);
+        acc[1][1] = mfma16h(a1h, b1l, acc[1][1]);
+        acc[0][0] = mfma16h(a0l, b0h, acc[0][0]);
+        acc[1][0] = mfma16h(a1l, b0h, acc[1][0]);
+        acc[0][1] = mfma16h(a0l, b1h, acc[0][1]);
+        acc[1][1] = mfma16h(a1l, b1h, acc[1][1]);
+      } else {
+        const f32x4 b0 = r0[j], b1 = r1[j];
+        r0[j] = W0[nx];
+        r1[j] = W1[nx];
+        const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+        const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
-        acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
-        acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
-        acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+        for (int s = 0; s < 4; ++s) {
+          acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
+          acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
+          acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
+          acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+        }
       }
     }
   }
@@ -497,40 +618,59 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
     const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
 #pragma unroll 4
     for (int rr = 0; rr < 16; ++rr) {
-      float* p = As + (wave * 16 + rr) * ST_LDA + lane * 4;
-      *(f32x4*)p = layernorm256(*(f32x4*)p, ga, gb);
+      float* row = As + (wave * 16 + rr) * ST_LDA;
+      panel_store4<H>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
     }
   }
   __syncthreads();
   // ---- phase 2: h = relu(xn . W1^T + b1), this wave's blocks wave, wave+4, ... ----
+  constexpr int R = 8;
   const int nblk = a.d_ff >> 5;
   const int cnt = (nblk - wave + 3) >> 2;
-  const int total = cnt * 32;
-  const float* Wl = a.w1 + (size_t)lane * 4;
-  auto wload = [&](int g) -> f32x4 {
+  const int total = cnt * SPB;
+  const f32x4* Wl = (const f32x4*)a.w1 + lane;
+  auto wload = [&](int g, int p) -> f32x4 {
     g = min(g, total - 1);
-    return *(const f32x4*)(Wl + ((size_t)(wave + 4 * (g >> 5)) * 32 + (g & 31)) * 256);
+    return Wl[(((size_t)(wave + 4 * (g / SPB)) * SPB + (g & (SPB - 1))) * F + p) * 64];
   };
-  f32x4 ring[8];
+  f32x4 ring[R], ringl[H ? R : 1];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ring[j] = wload(j);
+  for (int j = 0; j < R; ++j) {
+    ring[j] = wload(j, 0);
+    if (H) ringl[j] = wload(j, 1);
+  }
   f32x16 acc0 = {0}, acc1 = {0};
-  for (int g0 = 0; g0 < total; g0 += 8) {
+  for (int g0 = 0; g0 < total; g0 += R) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kg = (g0 + j) & 31;
-      const f32x4 b = ring[j];
-      ring[j] = wload(g0 + j + 8);
-      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
-      const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
+    for (int j = 0; j < R; ++j) {
+      const int kg = (g0 + j) & (SPB - 1);
+      if (H) {
+        const h8 bh = as_h8(ring[j]), bl = as_h8(ringl[j]);
+        ring[j] = wload(g0 + j + R, 0);
+        ringl[j] = wload(g0 + j + R, 1);
+        const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
+        const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
+        const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
+        acc0 = mfma16h(a0h, bh, acc0);
+        acc1 = mfma16h(a1h, bh, acc1);
+        acc0 = mfma16h(a0h, bl, acc0);
+        acc1 = mfma16h(a1h, bl, acc1);
+        acc0 = mfma16h(a0l, bh, acc0);
+        acc1 = mfma16h(a1l, bh, acc1);
+      } else {
+        const f32x4 b = ring[j];
+        ring[j] = wload(g0 + j + R, 0);
+        const f32x4 a0 = *(const f32x4*)(Ab + kg * 8);
+        const f32x4 a1 = *(const f32x4*)(Ab + 32 * ST_LDA + kg * 8);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc0 = mfma32(a0[s], b[s], acc0);
-        acc1 = mfma32(a1[s], b[s], acc1);
+        for (int s = 0; s < 4; ++s) {
+          acc0 = mfma32(a0[s], b[s], acc0);
+          acc1 = mfma32(a1[s], b[s], acc1);
+        }
       }
     }
-    if (((g0 + 8) & 31) == 0) {
-      const int col = ((wave + 4 * (g0 >> 5)) << 5) + l31;
+    if (((g0 + R) & (SPB - 1)) == 0) {
+      const int col = ((wave + 4 * (g0 / SPB)) << 5) + l31;
       const float bv = a.b1[col];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -548,20 +688,58 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
 }
 
 #define RP_FUSE_MIN_ROWS 65536  /* below this the unfused pair (with column splits) fills the chip better */
-static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
+template <bool H>
+static int launch_oproj_ffn1_t(const OFArgs& a, int n_bound, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_oproj_ffn1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
+    ST_HIP(hipFuncSetAttribute((const void*)rp_oproj_ffn1_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
     attr_done = true;
   }
   if (n_bound <= 0) return ST_OK;
-  hipLaunchKernelGGL(rp_oproj_ffn1_kernel<0>, dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
+  hipLaunchKernelGGL(rp_oproj_ffn1_kernel<H>, dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
+}
+static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
+  return a.fmt == ST_GEMM_F16X3 ? launch_oproj_ffn1_t<true>(a, n_bound, st) : launch_oproj_ffn1_t<false>(a, n_bound, st);
 }
 
 // packed-weight helpers -------------------------------------------------------------------------
 static inline size_t rp_packed_floats(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }
+
+// f16x3 image: one thread per 8 elements of W -> a hi and a lo h8
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void pack_weight_h_kernel(const float* __restrict__ W, int N, int K,
+                                                            float* __restrict__ out) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;  // (block, step, lane)
+  const int steps = K >> 4;
+  const size_t total = (size_t)((N + 31) / 32) * steps * 64;
+  if (o >= total) return;
+  const int lane = (int)(o & 63);
+  const int step = (int)((o >> 6) % steps);
+  const int blk = (int)((o >> 6) / steps);
+  const int row = blk * 32 + (lane & 31);
+  f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+  if (row < N) {
+    const float* src = W + (size_t)row * K + step * 16 + 8 * (lane >> 5);
+    v0 = *(const f32x4*)src;
+    v1 = *(const f32x4*)(src + 4);
+  }
+  h4 h0, l0, h1, l1;
+  split_f16(v0, h0, l0);
+  split_f16(v1, h1, l1);
+  h8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = h0[j];
+    hi[4 + j] = h1[j];
+    lo[j] = l0[j];
+    lo[4 + j] = l1[j];
+  }
+  h8* dst = (h8*)out + (((size_t)blk * steps + step) * 2) * 64 + lane;
+  dst[0] = hi;
+  dst[64] = lo;
+}
 
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ W, int N, int K,

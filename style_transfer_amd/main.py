@@ -91,6 +91,9 @@ def build_parser():
     g.add_argument('--log_file', type=str, default=None, help='log path (default ./loggings/<reference name>)')
     g.add_argument('--no_log_decodes', action='store_true', help='skip the Rec/Sim/Ref decodes (lines omitted)')
     g.add_argument('--fixed_decode_steps', action='store_true', help='always run max_sequence_length-1 decode steps')
+    g.add_argument('--gemm_format', default='f16x3', choices=['f16x3', 'f32'],
+                   help='autoencoder matrix products: f16x3 = f16 hi+lo split operands, 3 MFMA products per term, f32 '
+                        'accumulate (f32-grade results, default); f32 = exact f32 MFMA (~2x slower end to end)')
     g.add_argument('--quiet', action='store_true', help='do not echo log records on stdout')
     return p
 
@@ -192,7 +195,7 @@ def main(argv=None):
     id_to_word, vocab_size = load_word_dict_info(os.path.join(data_path, 'word_to_id.txt'), args.word_dict_max_num)
 
     ae_sd = W.load_state_dict_file(os.path.join(save_path, args.ae_checkpoint))
-    ae = W.AEWeights(ae_sd, device, max_len=args.max_sequence_length)
+    ae = W.AEWeights(ae_sd, device, max_len=args.max_sequence_length, gemm_format=args.gemm_format)
     if ae.vocab != vocab_size:
         raise ValueError("checkpoint vocabulary %d != word_to_id vocabulary %d" % (ae.vocab, vocab_size))
     # load_siamese (siamese_contrastive.py:1565-1587): exit(0) when a file is missing

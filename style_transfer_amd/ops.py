@@ -113,27 +113,36 @@ def scorer_edit_step(sw, latent, adam_m, adam_v, like_z, unlike_z, lr, step, act
     return loss, grad
 
 
-def pack_weight(W):
-    """nn.Linear weight [N,K] (device f32) -> MFMA-fragment-ordered image (st_pack_weight)."""
+def _fmt(gemm_format):
+    if isinstance(gemm_format, str):
+        if gemm_format not in _lib.GEMM_FORMATS:
+            raise ValueError("gemm_format %r: expected one of %s" % (gemm_format, sorted(_lib.GEMM_FORMATS)))
+        return _lib.GEMM_FORMATS[gemm_format]
+    return int(gemm_format)
+
+
+def pack_weight(W, gemm_format="f32"):
+    """nn.Linear weight [N,K] (device f32) -> MFMA-fragment-ordered image (st_pack_weight) for the
+    exact f32 kernels ("f32") or the 3-product f16 split kernels ("f16x3")."""
     _f32(W)
     N, K = W.shape
     out = torch.empty(lib().st_packed_weight_floats(N, K), dtype=torch.float32, device=W.device)
-    check(lib().st_pack_weight(W.data_ptr(), N, K, out.data_ptr(), _stream()), "st_pack_weight")
+    check(lib().st_pack_weight(W.data_ptr(), N, K, _fmt(gemm_format), out.data_ptr(), _stream()), "st_pack_weight")
     return out
 
 
-def gemm_argmax(h, W, b, ln_a=None, ln_b=None, packed=None):
-    """W [V,256] plain (packed here) or pass packed=pack_weight(W)."""
+def gemm_argmax(h, W, b, ln_a=None, ln_b=None, packed=None, gemm_format="f32"):
+    """W [V,256] plain (packed here) or pass packed=pack_weight(W, gemm_format)."""
     _f32(h); _f32(b)
     n, V = h.shape[0], b.shape[0]
     assert h.shape[1] == 256
-    W = packed if packed is not None else pack_weight(W)
+    W = packed if packed is not None else pack_weight(W, gemm_format)
     ids = torch.empty(n, dtype=torch.int32, device=h.device)
     best = torch.empty(n, dtype=torch.float32, device=h.device)
     gap = torch.empty(n, dtype=torch.float32, device=h.device)
     scratch = torch.empty(max(n, 1) * _lib.ST_ARGMAX_SPLITS * 16, dtype=torch.uint8, device=h.device)
-    check(lib().st_gemm_argmax(h.data_ptr(), _p(ln_a), _p(ln_b), W.data_ptr(), b.data_ptr(), n, V, ids.data_ptr(),
-                               best.data_ptr(), gap.data_ptr(), scratch.data_ptr(), _stream()), "st_gemm_argmax")
+    check(lib().st_gemm_argmax(h.data_ptr(), _p(ln_a), _p(ln_b), W.data_ptr(), b.data_ptr(), n, V, _fmt(gemm_format),
+                               ids.data_ptr(), best.data_ptr(), gap.data_ptr(), scratch.data_ptr(), _stream()), "st_gemm_argmax")
     return ids, best, gap
 
 

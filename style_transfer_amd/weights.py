@@ -44,8 +44,9 @@ def expand_ae_state_dict(sd: dict) -> dict:
 class _Packed:
     """Keeps the device tensors alive next to the ctypes struct that points at them."""
 
-    def __init__(self, device):
+    def __init__(self, device, gemm_format="f32"):
         self.device = device
+        self.gemm_format = gemm_format
         self._keep = []
 
     def dev(self, t: torch.Tensor) -> int:
@@ -56,16 +57,24 @@ class _Packed:
     def packed(self, t: torch.Tensor) -> int:
         """[N,K] Linear weight -> fragment-ordered device image (st_pack_weight)."""
         from . import ops
-        d = ops.pack_weight(t.detach().to(dtype=torch.float32).contiguous().to(self.device))
+        d = ops.pack_weight(t.detach().to(dtype=torch.float32).contiguous().to(self.device), self.gemm_format)
         self._keep.append(d)
         return d.data_ptr()
 
 
 class AEWeights(_Packed):
-    """Decoder + encoder weights of the Transformer autoencoder (model.py:302-324)."""
+    """Decoder + encoder weights of the Transformer autoencoder (model.py:302-324).
+    gemm_format: "f16x3" (default: 3-product f16 split on the f16 MFMA, f32-grade results) or "f32"
+    (exact f32 MFMA, ~3x slower)."""
 
-    def __init__(self, sd: dict, device, max_len: int = 60):
-        super().__init__(device)
+    def __init__(self, sd: dict, device, max_len: int = 60, gemm_format: str = "f16x3"):
+        super().__init__(device, gemm_format)
+        if gemm_format not in _lib.GEMM_FORMATS:
+            raise ValueError("gemm_format %r: expected one of %s" % (gemm_format, sorted(_lib.GEMM_FORMATS)))
+        if gemm_format == "f16x3":
+            big = max(float(v.abs().max()) for k, v in sd.items() if k.endswith(".weight") and v.dim() == 2)
+            if not big < 6.0e4:
+                raise _lib.StError("gemm_format f16x3 needs |W| < 65504 (max |W| = %g): use gemm_format='f32'" % big)
         sd = expand_ae_state_dict(sd)
         emb = sd["tgt_embed.0.lut.weight"]
         self.vocab, self.d_model = emb.shape
@@ -80,6 +89,7 @@ class AEWeights(_Packed):
         self.dec = _lib.StDecoderWeights()
         for s in (self.dec,):
             s.d_model, s.n_heads, s.d_ff, s.n_layers, s.vocab, s.pe_rows = self.d_model, 4, self.d_ff, self.n_layers, self.vocab, pe.shape[0]
+        self.dec.gemm_format = _lib.GEMM_FORMATS[gemm_format]
         self.dec.emb, self.dec.pe = self.emb_ptr, self.pe_ptr
         self.dec.lnf_a, self.dec.lnf_b = self.dev(sd["decoder.norm.a_2"]), self.dev(sd["decoder.norm.b_2"])
         self.dec.gen_w, self.dec.gen_b = self.packed(sd["generator.proj.weight"]), self.dev(sd["generator.proj.bias"])
@@ -99,6 +109,7 @@ class AEWeights(_Packed):
         s = self.enc
         n_enc = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
         s.d_model, s.n_heads, s.d_ff, s.n_layers, s.vocab, s.pe_rows = self.d_model, 4, self.d_ff, n_enc, self.vocab, pe.shape[0]
+        s.gemm_format = _lib.GEMM_FORMATS[gemm_format]
         s.emb, s.pe = self.emb_ptr, self.pe_ptr  # shared embedding; identical pe buffers
         s.lnf_a, s.lnf_b = self.dev(sd["encoder.norm.a_2"]), self.dev(sd["encoder.norm.b_2"])
         for l in range(n_enc):

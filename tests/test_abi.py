@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_loader_binds_and_reports_version():
     from style_transfer_amd import _lib
-    assert _lib.lib().st_abi_version() == 1
+    assert _lib.lib().st_abi_version() == _lib.ABI_VERSION
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

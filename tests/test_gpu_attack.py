@@ -19,15 +19,18 @@ LAT_RTOL = 1e-3     # relative to the sentence's max |latent| (north_star: "e.g.
 NEAR_TIE = 2e-3     # a decode may differ from the reference only where the reference's top-2 logit gap is below this
 
 
-@pytest.fixture(scope="module")
-def env(ae_sd_torch, scorer_sd_torch, id_to_word):
+FORMATS = ["f16x3", "f32"]  # the whole path is held to the same bars in both GEMM operand formats
+
+
+@pytest.fixture(scope="module", params=FORMATS)
+def env(request, ae_sd_torch, scorer_sd_torch, id_to_word):
     from style_transfer_amd import weights as W
     from style_transfer_amd.data import AttackSet
     dev = torch.device("cuda", 0)
-    ae = W.AEWeights(ae_sd_torch, dev)
+    ae = W.AEWeights(ae_sd_torch, dev, gemm_format=request.param)
     scorer = W.ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev)
     files = [os.path.join(GOLD, "yelp", "neg10_pos10_test%d.json" % i) for i in (0, 1)]
-    return dict(dev=dev, ae=ae, scorer=scorer, files=files, V=len(id_to_word), id_to_word=id_to_word)
+    return dict(dev=dev, ae=ae, scorer=scorer, files=files, V=len(id_to_word), id_to_word=id_to_word, fmt=request.param)
 
 
 def run(env, g, log_decodes=False, pos_num=None, neg_num=None, **flags):
@@ -142,7 +145,7 @@ def test_cli_full_yelp_test_set_batch256(env, gold_notnll, tmp_path, capsys):
     log = tmp_path / "yelp_log"
     rc = M.main(["--attack", "--not_nll", "--pos_victim_lr=0.2", "--neg_victim_lr=0.2", "--save_path", GOLD + "/",
                  "--data_path", os.path.join(GOLD, "yelp") + "/", "--ae_checkpoint", "surrogate_ae_yelp.safetensors",
-                 "--attack_batch", "256", "--quiet", "--log_file", str(log)])
+                 "--attack_batch", "256", "--quiet", "--log_file", str(log), "--gemm_format", env["fmt"]])
     assert rc == 0
     lines = open(log).read().splitlines()
     out = extract_out(lines, 2, 2)
@@ -167,7 +170,8 @@ def test_not_nll_with_unequal_counts_is_rejected_like_the_reference(env):
         r.run_batch(data, [0, 1])
 
 
-def test_attack_amazon_matches_reference(scorer_sd_torch):
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_attack_amazon_matches_reference(scorer_sd_torch, fmt):
     """BASELINE config 3: amazon test split (origins 9-15 tokens, refs/sims up to 31: the general
     encoder-attention kernel and decode prefixes beyond 16 keys), V = 19724.  No amazon weights ship, so the
     golden run used a second surrogate AE (tests/golden/surrogate_ae_amazon.safetensors, fp16-rounded) and the
@@ -179,7 +183,7 @@ def test_attack_amazon_matches_reference(scorer_sd_torch):
     from style_transfer_amd import weights as W
     from style_transfer_amd.data import load_word_dict_info
     dev = torch.device("cuda", 0)
-    ae = W.AEWeights(W.load_state_dict_file(ck), dev)
+    ae = W.AEWeights(W.load_state_dict_file(ck), dev, gemm_format=fmt)
     scorer = W.ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev)
     id_to_word, V = load_word_dict_info(os.path.join(GOLD, "amazon", "word_to_id.txt"), 5)
     assert V == 19724 == ae.vocab

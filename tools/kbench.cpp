@@ -27,11 +27,17 @@ static float* dev_rand(size_t n, float scale, unsigned seed) {
   CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
   return d;
 }
+static int g_fmt = ST_GEMM_F32;
 static float* pack(const float* W, int N, int K) {
   float* out;
   CK(hipMalloc(&out, rp_packed_floats(N, K) * 4));
-  size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
-  hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, W, N, K, out);
+  if (g_fmt == ST_GEMM_F16X3) {
+    size_t total = (size_t)((N + 31) / 32) * (K >> 4) * 64;
+    hipLaunchKernelGGL(pack_weight_h_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, W, N, K, out);
+  } else {
+    size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
+    hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, W, N, K, out);
+  }
   CK(hipDeviceSynchronize());
   return out;
 }
@@ -52,6 +58,8 @@ static double timeit(F f, int iters = 10) {
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 65536;
+  g_fmt = argc > 3 ? atoi(argv[3]) : ST_GEMM_F32;  // kbench <rows> <generator splits, 0 = auto> <format>
+  printf("gemm_format %d\n", g_fmt);
   const int V = 9339, DFF = 1024;
   float* x = dev_rand((size_t)n * 256, 1.0f, 1);
   float* att = dev_rand((size_t)n * 256, 1.0f, 2);
@@ -76,13 +84,15 @@ int main(int argc, char** argv) {
 
   {  // generator
     GemmArgs g = {};
+    g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
-    const int sp = argc > 2 ? atoi(argv[2]) : rp_splits(n, V, 16);
+    const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(n, V, 16);
     t = timeit([&] { launch_rp<EPI_ARGMAX>(g, n, sp, st); });
     printf("generator  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
   }
   {  // FFN1 (rp RELU)
     GemmArgs g = {};
+    g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = w1_p; g.bias = bias; g.N = DFF; g.out = h; g.ldo = DFF;
     const int sp = rp_splits(n, DFF, 8);
     t = timeit([&] { launch_rp<EPI_RELU>(g, n, sp, st); });
@@ -92,6 +102,7 @@ int main(int argc, char** argv) {
   }
   {  // QKV as plain BIAS store to [n,768]
     GemmArgs g = {};
+    g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wqkv_p; g.bias = bias; g.N = 768; g.out = q; g.ldo = 768;
     const int sp = rp_splits(n, 768, 6);
     t = timeit([&] { launch_rp<EPI_BIAS>(g, n, sp, st); });
@@ -101,6 +112,7 @@ int main(int argc, char** argv) {
   }
   {  // O-proj RESID
     GemmArgs g = {};
+    g.fmt = g_fmt;
     g.X = att; g.n_host = n; g.W = wo_p; g.bias = bias; g.N = 256; g.out = x; g.ldo = 256; g.resid = x;
     const int sp = rp_splits(n, 256, 2);
     t = timeit([&] { launch_rp<EPI_RESID>(g, n, sp, st); });
@@ -108,12 +120,14 @@ int main(int argc, char** argv) {
   }
   {  // FFN2 kchunk
     GemmArgs g = {};
+    g.fmt = g_fmt;
     g.X = h; g.n_host = n; g.K = DFF; g.W = w2_p; g.bias = bias; g.N = 256; g.out = x; g.ldo = 256; g.resid = x;
     t = timeit([&] { launch_rp_kchunk<EPI_RESID>(g, n, st); });
     printf("ffn2       n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * DFF / t / 1e12);
   }
   {  // fused O + FFN1
     OFArgs a = {};
+    a.fmt = g_fmt;
     a.att = att; a.n_host = n; a.wo = wo_p; a.bo = bias; a.x = x; a.ln_a = ln_a; a.ln_b = ln_b; a.w1 = w1_p; a.b1 = bias;
     a.h = h; a.d_ff = DFF;
     t = timeit([&] { launch_oproj_ffn1(a, n, st); });
