@@ -360,7 +360,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
-      ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, rp_splits(n_bound, 768, 3, 8), st)));
+      ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, rp_splits(n_bound, 768, 3, rp_nw(w->gemm_format, 8)), st)));
       if (pos < 16)
         hipLaunchKernelGGL(attn_step16_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
                            n_dev, pos, ws.att);
@@ -368,12 +368,16 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
                            ws.att);
       ST_LAUNCH_CHECK();
+      OFArgs of = {};
+      of.fmt = w->gemm_format;
+      of.att = ws.att; of.n_dev = n_dev; of.n_host = n_bound; of.wo = y.wo; of.bo = y.bo; of.x = ws.x;
+      of.cconst = ws.cc + (size_t)l * B * 256; of.idx = idx; of.ln_a = y.ln2_a; of.ln_b = y.ln2_b;
+      of.w1 = y.w1; of.b1 = y.b1; of.h = ws.h; of.d_ff = w->d_ff; of.w2 = y.w2; of.b2 = y.b2;
+      if (w->gemm_format == ST_GEMM_F16X3 && n_bound >= RP_TAIL_MIN_ROWS) {
+        ST_TRY(launch_layer_tail(of, n_bound, st));  // O-projection + FFN in one kernel
+        continue;
+      }
       if (n_bound >= RP_FUSE_MIN_ROWS) {
-        OFArgs of = {};
-        of.fmt = w->gemm_format;
-        of.att = ws.att; of.n_dev = n_dev; of.n_host = n_bound; of.wo = y.wo; of.bo = y.bo; of.x = ws.x;
-        of.cconst = ws.cc + (size_t)l * B * 256; of.idx = idx; of.ln_a = y.ln2_a; of.ln_b = y.ln2_b;
-        of.w1 = y.w1; of.b1 = y.b1; of.h = ws.h; of.d_ff = w->d_ff;
         ST_TRY(launch_oproj_ffn1(of, n_bound, st));
       } else {
         GemmArgs o = {};
@@ -385,7 +389,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         f1.fmt = w->gemm_format;
         f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
         f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
-        ST_TRY((launch_rp<EPI_RELU, 8>(f1, n_bound, rp_splits(n_bound, w->d_ff, 4, 8), st)));
+        ST_TRY((launch_rp<EPI_RELU, 8>(f1, n_bound, rp_splits(n_bound, w->d_ff, 4, rp_nw(w->gemm_format, 8)), st)));
       }
       GemmArgs f2 = {};
       f2.fmt = w->gemm_format;

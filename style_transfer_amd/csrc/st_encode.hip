@@ -174,15 +174,19 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     g.fmt = w->gemm_format;
     g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
     g.out = qkv; g.ldo = 768;
-    ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, rp_splits(R, 768, 3, 8), st)));
+    ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, rp_splits(R, 768, 3, rp_nw(w->gemm_format, 8)), st)));
     hipLaunchKernelGGL(enc_attn16_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
     if (max_sent_len > 16) hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
     ST_LAUNCH_CHECK();
+    OFArgs of = {};
+    of.fmt = w->gemm_format;
+    of.att = att; of.n_host = R; of.wo = y.wo; of.bo = y.bo; of.x = x; of.ln_a = y.ln1_a; of.ln_b = y.ln1_b;
+    of.w1 = y.w1; of.b1 = y.b1; of.h = h; of.d_ff = w->d_ff; of.w2 = y.w2; of.b2 = y.b2;
+    if (w->gemm_format == ST_GEMM_F16X3 && R >= RP_TAIL_MIN_ROWS) {
+      ST_TRY(launch_layer_tail(of, R, st));  // O-projection + FFN in one kernel
+      continue;
+    }
     if (R >= RP_FUSE_MIN_ROWS) {
-      OFArgs of = {};
-      of.fmt = w->gemm_format;
-      of.att = att; of.n_host = R; of.wo = y.wo; of.bo = y.bo; of.x = x; of.ln_a = y.ln1_a; of.ln_b = y.ln1_b;
-      of.w1 = y.w1; of.b1 = y.b1; of.h = h; of.d_ff = w->d_ff;
       ST_TRY(launch_oproj_ffn1(of, R, st));
     } else {
       GemmArgs o = {};
@@ -193,7 +197,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       f1.fmt = w->gemm_format;
       f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
       f1.out = h; f1.ldo = w->d_ff;
-      ST_TRY((launch_rp<EPI_RELU, 8>(f1, R, rp_splits(R, w->d_ff, 4, 8), st)));
+      ST_TRY((launch_rp<EPI_RELU, 8>(f1, R, rp_splits(R, w->d_ff, 4, rp_nw(w->gemm_format, 8)), st)));
     }
     GemmArgs f2 = {};
     f2.fmt = w->gemm_format;

@@ -22,7 +22,9 @@
 
 // streaming outputs (written once, read by a later kernel): nontemporal stores keep them from evicting
 // the L2-resident weights
-#ifdef ST_NO_NT
+#if defined(ST_ABL_NOSTORE)  /* kbench ablation: keep the value live, never store */
+#define ST_STORE(ptr, v) do { if ((v) == 1.2345e-30f) *(ptr) = (v); } while (0)
+#elif defined(ST_NO_NT)
 #define ST_STORE(ptr, v) (*(ptr) = (v))
 #else
 #define ST_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   const int n = a.n_dev ? *a.n_dev : a.n_host;
   const int m0 = blockIdx.x * 64;
   if (m0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the W address math on the scalar unit
   const int half = lane >> 5, l31 = lane & 31;
 
   // ---- X panel -> LDS (64 rows x 64 float4, 16 per thread), optional LayerNorm ----
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
 
   // this workgroup's column blocks [b0, b1), this wave's: b0 + wave + NW*i
   constexpr int SPB = H ? 16 : 32;              // ring steps per 32-column block (K = 256)
-  constexpr int R = H ? (NW == 8 ? 4 : 8) : 8;  // ring depth in steps
+  constexpr int R = 8;                          // ring depth in steps
   const int nblk = (a.N + 31) >> 5;
   const int per = (nblk + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per;
@@ -125,9 +128,25 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
     }
   }
   const float* Ab = As + l31 * ST_LDA + 4 * half;
-  f32x16 acc0 = {0}, acc1 = {0};
+  // accumulators start from the column's bias (fetched one block ahead) instead of zero
+  auto bias_of = [&](int i) -> float {
+    const int col = ((b0 + wave + NW * i) << 5) + l31;
+    return (a.bias && col < a.N) ? a.bias[col] : 0.0f;
+  };
+  float bnext = cnt > 0 ? bias_of(0) : 0.0f;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bnext;
   float pre[2][16];  // RESID: residual (+ cross-attention constant), fetched while the block's MFMAs run
+  f32x4 an[H ? 4 : 1];
+  if (H) {
+    an[0] = *(const f32x4*)(Ab);
+    an[1] = *(const f32x4*)(Ab + 128);
+    an[2] = *(const f32x4*)(Ab + 32 * ST_LDA);
+    an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
+  }
   for (int g0 = 0; g0 < total; g0 += R) {
+    if ((g0 & (SPB - 1)) == 0) bnext = bias_of(g0 / SPB + 1);
     if (EPI == EPI_RESID && (g0 & (SPB - 1)) == 0) {
       const int col = min(((b0 + wave + NW * (g0 / SPB)) << 5) + l31, a.N - 1);
 #pragma unroll
@@ -147,9 +166,13 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
         const h8 bh = as_h8(ring[j]), bl = as_h8(ringl[j]);
         ring[j] = wload(g0 + j + R, 0);
         ringl[j] = wload(g0 + j + R, 1);
-        const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
-        const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
-        const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
+        // A fragments of the NEXT step are requested before this step's MFMAs (LDS latency ~ one step)
+        const h8 a0h = as_h8(an[0]), a0l = as_h8(an[1]), a1h = as_h8(an[2]), a1l = as_h8(an[3]);
+        const int kn = (kg + 1) & (SPB - 1);
+        an[0] = *(const f32x4*)(Ab + kn * 8);
+        an[1] = *(const f32x4*)(Ab + 128 + kn * 8);
+        an[2] = *(const f32x4*)(Ab + 32 * ST_LDA + kn * 8);
+        an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128 + kn * 8);
         acc0 = mfma16h(a0h, bh, acc0);
         acc1 = mfma16h(a1h, bh, acc1);
         acc0 = mfma16h(a0h, bl, acc0);
@@ -172,19 +195,20 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
       // ---- epilogue for this wave's column block ----
       const int col = ((b0 + wave + NW * (g0 / SPB)) << 5) + l31;
       const bool colok = col < a.N;
-      const float bv = (colok && a.bias) ? a.bias[col] : 0.0f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const f32x16 acc = mi ? acc1 : acc0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + mi * 32 + mfma32_row(r, lane);
-          float v = acc[r] + bv;
+          float v = acc[r];
           if (EPI == EPI_ARGMAX) {
             v = colok ? v : -INFINITY;
             Top2& t = best[mi][r];
             const bool gt = v > t.m1;
+#ifndef ST_ABL_NOGAP
             t.m2 = gt ? t.m1 : fmaxf(t.m2, v);
+#endif
             t.i1 = gt ? col : t.i1;
             t.m1 = gt ? v : t.m1;
           } else if (EPI == EPI_LSE) {
@@ -219,8 +243,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
           }
         }
       }
-      acc0 = (f32x16){0};
-      acc1 = (f32x16){0};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bnext;
     }
   }
 
@@ -327,9 +351,12 @@ static int launch_rp_t(const GemmArgs& a, int n_bound, int splits, hipStream_t s
   return ST_OK;
 }
 // a.fmt selects the operand format the packed W image was built for (ST_GEMM_F32 / ST_GEMM_F16X3)
+// NW is the wave count of the f32 kernel; the f16x3 kernels always run 4 waves (2 workgroups x 4 waves with
+// 256 registers each measured faster than 8-wave workgroups at 128: QKV 199 vs 242 us at 131072 rows)
+static inline int rp_nw(int fmt, int nw_f32) { return fmt == ST_GEMM_F16X3 ? 4 : nw_f32; }
 template <int EPI, int NW = 4>
 static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
-  return a.fmt == ST_GEMM_F16X3 ? launch_rp_t<EPI, NW, true>(a, n_bound, splits, st)
+  return a.fmt == ST_GEMM_F16X3 ? launch_rp_t<EPI, 4, true>(a, n_bound, splits, st)
                                 : launch_rp_t<EPI, NW, false>(a, n_bound, splits, st);
 }
 
@@ -345,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
   const int n = a.n_dev ? *a.n_dev : a.n_host;
   const int m0 = blockIdx.x * 64;
   if (m0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the W address math on the scalar unit
   const int half = lane >> 5, l31 = lane & 31;
   constexpr int SPC = H ? 16 : 32;  // ring steps per 256-wide K chunk
   constexpr int F = H ? 2 : 1;      // fragments per step
@@ -504,9 +532,10 @@ struct OFArgs {
   const int* idx;
   const float *ln_a, *ln_b;      // LayerNorm before the FFN
   const float *w1, *b1;          // packed [d_ff,256], [d_ff]
-  float* h;                      // [n,d_ff]
+  float* h;                      // [n,d_ff]   (rp_oproj_ffn1_kernel only)
   int d_ff;
-  int fmt;                       // operand format of wo / w1 (ST_GEMM_F32 / ST_GEMM_F16X3)
+  int fmt;                       // operand format of wo / w1 / w2 (ST_GEMM_F32 / ST_GEMM_F16X3)
+  const float *w2, *b2;          // packed [256,d_ff], [256]   (rp_layer_tail_kernel only)
 };
 
 template <bool H = false>
@@ -516,7 +545,8 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
   const int n = a.n_dev ? *a.n_dev : a.n_host;
   const int m0 = blockIdx.x * 64;
   if (m0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the W address math on the scalar unit
   const int half = lane >> 5, l31 = lane & 31;
   constexpr int SPB = H ? 16 : 32;  // ring steps per 32-column block (K = 256)
   constexpr int F = H ? 2 : 1;      // fragments per step
@@ -640,6 +670,13 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
     if (H) ringl[j] = wload(j, 1);
   }
   f32x16 acc0 = {0}, acc1 = {0};
+  f32x4 an[H ? 4 : 1];
+  if (H) {
+    an[0] = *(const f32x4*)(Ab);
+    an[1] = *(const f32x4*)(Ab + 128);
+    an[2] = *(const f32x4*)(Ab + 32 * ST_LDA);
+    an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
+  }
   for (int g0 = 0; g0 < total; g0 += R) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -648,9 +685,13 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
         const h8 bh = as_h8(ring[j]), bl = as_h8(ringl[j]);
         ring[j] = wload(g0 + j + R, 0);
         ringl[j] = wload(g0 + j + R, 1);
-        const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
-        const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
-        const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
+        // A fragments of the NEXT step are requested before this step's MFMAs (LDS latency ~ one step)
+        const h8 a0h = as_h8(an[0]), a0l = as_h8(an[1]), a1h = as_h8(an[2]), a1l = as_h8(an[3]);
+        const int kn = (kg + 1) & (SPB - 1);
+        an[0] = *(const f32x4*)(Ab + kn * 8);
+        an[1] = *(const f32x4*)(Ab + 128 + kn * 8);
+        an[2] = *(const f32x4*)(Ab + 32 * ST_LDA + kn * 8);
+        an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128 + kn * 8);
         acc0 = mfma16h(a0h, bh, acc0);
         acc1 = mfma16h(a1h, bh, acc1);
         acc0 = mfma16h(a0h, bl, acc0);
@@ -702,6 +743,199 @@ static int launch_oproj_ffn1_t(const OFArgs& a, int n_bound, hipStream_t st) {
 }
 static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
   return a.fmt == ST_GEMM_F16X3 ? launch_oproj_ffn1_t<true>(a, n_bound, st) : launch_oproj_ffn1_t<false>(a, n_bound, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole post-attention half-layer in one kernel (f16x3 format):
+//   x1 = att.Wo^T + bo + x (+ cross-attention constant);   x <- x1 + relu(LayerNorm(x1).W1^T + b1).W2^T + b2
+// One 64-row panel per workgroup of 8 waves; the hidden activations never leave the CU.  LDS holds two
+// split-f16 panels (133 KiB, one workgroup per CU): P1 = attention output, then x1, then LayerNorm(x1);
+// P2 = one 256-wide chunk of the hidden layer.  Wave w owns output column block w: x1 lives in its
+// accumulators (32 registers) from the O-projection to the final store and receives the FFN2 partial
+// sums chunk by chunk.  FFN1 is computed TRANSPOSED (W1 fragment as the A operand, x fragment as B), so a
+// lane ends up holding 4 consecutive hidden units of ONE row per accumulator group and writes them to P2
+// as packed halves (ds_write_b64) in exactly the layout the FFN2 A fragments are read from.
+// HBM traffic per row: att + x in, x out (3 KiB) instead of 13 KiB for the unfused chain.
+// ------------------------------------------------------------------------------------------------
+#define RP_TAIL_LDS (2 * 64 * ST_LDA * 4)
+#define RP_TAIL_MIN_ROWS 4096  /* below this the unfused kernels (column splits) fill the chip better */
+#define RP_TAIL_MMA6(ACC0, ACC1, A0H, A0L, A1H, A1L, BH, BL) \
+  ACC0 = mfma16h(A0H, BH, ACC0);                             \
+  ACC1 = mfma16h(A1H, BH, ACC1);                             \
+  ACC0 = mfma16h(A0H, BL, ACC0);                             \
+  ACC1 = mfma16h(A1H, BL, ACC1);                             \
+  ACC0 = mfma16h(A0L, BH, ACC0);                             \
+  ACC1 = mfma16h(A1L, BH, ACC1);
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* P1 = smem;
+  float* P2 = smem + 64 * ST_LDA;
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int col = wave * 32 + l31;  // this lane's output column (O-projection and FFN2)
+  const int nchunk = a.d_ff >> 8;
+
+  // 16 k-steps of one 32-column block: fragments (hi, lo) through a 4-deep register ring
+  f32x4 rh[4], rl[4];
+  auto ring_fill = [&](const f32x4* Wb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rh[j] = Wb[(size_t)j * 128];
+      rl[j] = Wb[(size_t)j * 128 + 64];
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = tid + i * 512;
+    const int r = f >> 6, c4 = f & 63;
+    panel_store4<true>(P1 + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
+  }
+  // ---- O-projection; accumulators start from bias + residual (+ constant) ----
+  const f32x4* Wo = (const f32x4*)a.wo + (size_t)wave * 16 * 128 + lane;
+  ring_fill(Wo);
+  f32x16 ax0, ax1;
+  {
+    const float bv = a.bo[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row0 = min(m0 + mfma32_row(r, lane), n - 1), row1 = min(m0 + 32 + mfma32_row(r, lane), n - 1);
+      float v0 = bv + a.x[(size_t)row0 * 256 + col], v1 = bv + a.x[(size_t)row1 * 256 + col];
+      if (a.cconst) {
+        v0 += a.cconst[(size_t)a.idx[row0] * 256 + col];
+        v1 += a.cconst[(size_t)a.idx[row1] * 256 + col];
+      }
+      ax0[r] = v0;
+      ax1[r] = v1;
+    }
+  }
+  __syncthreads();
+  const float* A1 = P1 + l31 * ST_LDA + 4 * half;  // fragment base in P1 (rows l31 and l31 + 32)
+  const float* A2 = P2 + l31 * ST_LDA + 4 * half;
+  // one 16-step pass: standard orientation (panel rows x W columns) or transposed (W rows x panel rows)
+  auto pass = [&](const float* Ab, const f32x4* Wb, f32x16& c0, f32x16& c1, bool transposed) {
+    for (int g0 = 0; g0 < 16; g0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kg = g0 + j;
+        const h8 bh = as_h8(rh[j]), bl = as_h8(rl[j]);
+        const int nx = min(kg + 4, 15);
+        rh[j] = Wb[(size_t)nx * 128];
+        rl[j] = Wb[(size_t)nx * 128 + 64];
+        const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
+        const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
+        const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
+        if (transposed) {
+          c0 = mfma16h(bh, a0h, c0);
+          c1 = mfma16h(bh, a1h, c1);
+          c0 = mfma16h(bl, a0h, c0);
+          c1 = mfma16h(bl, a1h, c1);
+          c0 = mfma16h(bh, a0l, c0);
+          c1 = mfma16h(bh, a1l, c1);
+        } else {
+          RP_TAIL_MMA6(c0, c1, a0h, a0l, a1h, a1l, bh, bl)
+        }
+      }
+    }
+  };
+  pass(A1, Wo, ax0, ax1, false);
+  __syncthreads();  // every wave is done reading the attention panel
+  // ---- x1 -> P1 (f32), LayerNorm + split in place ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    P1[(mfma32_row(r, lane)) * ST_LDA + col] = ax0[r];
+    P1[(32 + mfma32_row(r, lane)) * ST_LDA + col] = ax1[r];
+  }
+  const f32x4* W1b = (const f32x4*)a.w1 + (size_t)wave * 16 * 128 + lane;  // hidden block (chunk*8 + wave)
+  ring_fill(W1b);
+  __syncthreads();
+  {
+    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+#pragma unroll 4
+    for (int rr = 0; rr < 8; ++rr) {
+      float* row = P1 + (wave * 8 + rr) * ST_LDA;
+      panel_store4<true>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
+    }
+  }
+  {
+    const float b2v = a.b2[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ax0[r] += b2v;
+      ax1[r] += b2v;
+    }
+  }
+  __syncthreads();
+  _Float16* H2 = (_Float16*)P2;
+  for (int c = 0; c < nchunk; ++c) {
+    // ---- FFN1, hidden block jb = 8c + wave, transposed: lane = panel row, registers = hidden units ----
+    const int jb = c * 8 + wave;
+    f32x16 ah0, ah1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bb = *(const f32x4*)(a.b1 + jb * 32 + 8 * g + 4 * half);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ah0[4 * g + q] = ah1[4 * g + q] = bb[q];
+    }
+    pass(A1, W1b, ah0, ah1, true);
+    // next ring: this wave's W2 fragments for chunk c (k-steps 16c .. 16c+15 of output block `wave`)
+    const f32x4* W2b = (const f32x4*)a.w2 + ((size_t)wave * (a.d_ff >> 4) + c * 16) * 128 + lane;
+    ring_fill(W2b);
+    if (c > 0) __syncthreads();  // every wave is done reading the previous hidden chunk
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v0, v1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v0[q] = fmaxf(ah0[4 * g + q], 0.0f);
+        v1[q] = fmaxf(ah1[4 * g + q], 0.0f);
+      }
+      h4 hi, lo;
+      const int jl = wave * 32 + 8 * g + 4 * half;
+      split_f16(v0, hi, lo);
+      *(h4*)(H2 + (size_t)l31 * (2 * ST_LDA) + jl) = hi;
+      *(h4*)(H2 + (size_t)l31 * (2 * ST_LDA) + 256 + jl) = lo;
+      split_f16(v1, hi, lo);
+      *(h4*)(H2 + (size_t)(32 + l31) * (2 * ST_LDA) + jl) = hi;
+      *(h4*)(H2 + (size_t)(32 + l31) * (2 * ST_LDA) + 256 + jl) = lo;
+    }
+    __syncthreads();  // hidden chunk complete
+    // ---- FFN2 partial: x += h_c . W2[:, chunk]^T ----
+    pass(A2, W2b, ax0, ax1, false);
+    if (c + 1 < nchunk) {
+      W1b = (const f32x4*)a.w1 + (size_t)((c + 1) * 8 + wave) * 16 * 128 + lane;
+      ring_fill(W1b);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row0 = m0 + mfma32_row(r, lane), row1 = row0 + 32;
+    if (row0 < n) ST_STORE(&a.x[(size_t)row0 * 256 + col], ax0[r]);
+    if (row1 < n) ST_STORE(&a.x[(size_t)row1 * 256 + col], ax1[r]);
+  }
+}
+
+static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)rp_layer_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_TAIL_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  if (a.fmt != ST_GEMM_F16X3 || a.d_ff % 256 != 0 || !a.w2 || !a.b2) {
+    st_set_error("rp_layer_tail: needs the f16x3 format, d_ff %% 256 == 0 and w2/b2 (fmt=%d d_ff=%d)", a.fmt, a.d_ff);
+    return ST_EINVAL;
+  }
+  hipLaunchKernelGGL(rp_layer_tail_kernel<0>, dim3((n_bound + 63) / 64), dim3(512), RP_TAIL_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
 }
 
 // packed-weight helpers -------------------------------------------------------------------------

@@ -59,6 +59,8 @@ static double timeit(F f, int iters = 10) {
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 65536;
   g_fmt = argc > 3 ? atoi(argv[3]) : ST_GEMM_F32;  // kbench <rows> <generator splits, 0 = auto> <format>
+  const char* only = argc > 4 ? argv[4] : "gfqo2ut";  // which kernels: g f q o 2 u
+  auto want = [&](char c) { return strchr(only, c) != nullptr; };
   printf("gemm_format %d\n", g_fmt);
   const int V = 9339, DFF = 1024;
   float* x = dev_rand((size_t)n * 256, 1.0f, 1);
@@ -82,7 +84,7 @@ int main(int argc, char** argv) {
   hipStream_t st = 0;
   double t;
 
-  {  // generator
+  if (want('g')) {  // generator
     GemmArgs g = {};
     g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
@@ -90,7 +92,7 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_rp<EPI_ARGMAX>(g, n, sp, st); });
     printf("generator  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
   }
-  {  // FFN1 (rp RELU)
+  if (want('f')) {  // FFN1 (rp RELU)
     GemmArgs g = {};
     g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = w1_p; g.bias = bias; g.N = DFF; g.out = h; g.ldo = DFF;
@@ -100,7 +102,7 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_rp<EPI_RELU, 8>(g, n, sp, st); });
     printf("ffn1 NW=8  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * DFF / t / 1e12);
   }
-  {  // QKV as plain BIAS store to [n,768]
+  if (want('q')) {  // QKV as plain BIAS store to [n,768]
     GemmArgs g = {};
     g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wqkv_p; g.bias = bias; g.N = 768; g.out = q; g.ldo = 768;
@@ -110,7 +112,7 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_rp<EPI_BIAS, 8>(g, n, sp, st); });
     printf("qkv NW=8   n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
   }
-  {  // O-proj RESID
+  if (want('o')) {  // O-proj RESID
     GemmArgs g = {};
     g.fmt = g_fmt;
     g.X = att; g.n_host = n; g.W = wo_p; g.bias = bias; g.N = 256; g.out = x; g.ldo = 256; g.resid = x;
@@ -118,20 +120,28 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_rp<EPI_RESID>(g, n, sp, st); });
     printf("oproj      n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 256 / t / 1e12);
   }
-  {  // FFN2 kchunk
+  if (want('2')) {  // FFN2 kchunk
     GemmArgs g = {};
     g.fmt = g_fmt;
     g.X = h; g.n_host = n; g.K = DFF; g.W = w2_p; g.bias = bias; g.N = 256; g.out = x; g.ldo = 256; g.resid = x;
     t = timeit([&] { launch_rp_kchunk<EPI_RESID>(g, n, st); });
     printf("ffn2       n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * DFF / t / 1e12);
   }
-  {  // fused O + FFN1
+  if (want('u')) {  // fused O + FFN1
     OFArgs a = {};
     a.fmt = g_fmt;
     a.att = att; a.n_host = n; a.wo = wo_p; a.bo = bias; a.x = x; a.ln_a = ln_a; a.ln_b = ln_b; a.w1 = w1_p; a.b1 = bias;
     a.h = h; a.d_ff = DFF;
     t = timeit([&] { launch_oproj_ffn1(a, n, st); });
     printf("oproj+ffn1 n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + DFF) / t / 1e12);
+  }
+  if (want('t') && g_fmt == ST_GEMM_F16X3) {  // whole post-attention half-layer
+    OFArgs a = {};
+    a.fmt = g_fmt;
+    a.att = att; a.n_host = n; a.wo = wo_p; a.bo = bias; a.x = x; a.ln_a = ln_a; a.ln_b = ln_b; a.w1 = w1_p; a.b1 = bias;
+    a.w2 = w2_p; a.b2 = bias; a.d_ff = DFF;
+    t = timeit([&] { launch_layer_tail(a, n, st); });
+    printf("layer tail n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + 2 * DFF) / t / 1e12);
   }
 #ifdef HAVE_LAYER_FUSED
   {
