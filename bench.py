@@ -123,7 +123,7 @@ def main():
     for _ in range(a.warmup):
         runner.run_prepared(prep, gidx, fetch=False)
     sync()
-    L.st_profile_enable(1)
+    L.st_profile_enable(_lib.ST_PROF_HALF_LAYER if a.gemm_format == "f16x3" else _lib.ST_PROF_GENERATOR)
     units = 0
     setup_s = loop_s = 0.0
     t0 = time.perf_counter()

@@ -40,13 +40,18 @@ extern "C" {
 int st_abi_version(void);
 const char* st_last_error(void);
 
-/* Timing of the dominant kernel (generator GEMM + argmax) with HIP events on the caller's stream,
- * for bench.py's roofline line (no reference counterpart).  While enabled, st_decode_greedy brackets
- * every generator launch with an event pair; st_profile_read waits for them and returns the summed
- * kernel milliseconds, the summed algorithmic flops (2 * live_rows * 256 * V per launch; exact when
- * sync_every == 1) and the launch count; reset != 0 clears the record.                           */
-int st_profile_enable(int on);
-int st_profile_read(double* gen_ms, double* gen_flops, long long* gen_launches, int reset);
+/* Timing of one kernel of st_decode_greedy with HIP events on the caller's stream, for bench.py's
+ * roofline line (no reference counterpart).  While enabled, every launch of the selected kernel is
+ * bracketed with an event pair; st_profile_read waits for them and returns the summed kernel
+ * milliseconds, the summed algorithmic flops and the launch count; reset != 0 clears the record.
+ *   ST_PROF_GENERATOR  : generator GEMM + argmax (both passes when screened); 2 * live_rows * 256 * V flops
+ *   ST_PROF_HALF_LAYER : the fused post-attention half-layer (f16x3 format); 2 * live_rows * 256 * (256 + 2 d_ff)
+ * (live_rows is exact when sync_every == 1).                                                      */
+#define ST_PROF_OFF 0
+#define ST_PROF_GENERATOR 1
+#define ST_PROF_HALF_LAYER 2
+int st_profile_enable(int which);
+int st_profile_read(double* ms, double* flops, long long* launches, int reset);
 
 /* Weight packing (no reference counterpart).  The GEMM kernels read nn.Linear weight matrices
  * W [N,K] row-major in MFMA-fragment order so that every wave load is one coalesced 1 KiB read.
@@ -121,7 +126,9 @@ typedef struct StDecLayer {
 
 typedef struct StDecoderWeights {
   int32_t d_model, n_heads, d_ff, n_layers, vocab, pe_rows;
-  int32_t gemm_format, reserved0;      /* ST_GEMM_*: format of every PACKED field below          */
+  int32_t gemm_format;                 /* ST_GEMM_*: format of every PACKED field below          */
+  float gen_w_maxnorm;                 /* max_v ||generator.proj.weight[v]||_2 (host-computed); > 0 enables the
+                                          screened argmax of the f16x3 format, 0 = always the full product */
   const float* emb;                    /* tgt_embed.0.lut.weight [V,256]                        */
   const float* pe;                     /* tgt_embed.1.pe [pe_rows,256]                          */
   const float *lnf_a, *lnf_b;          /* decoder.norm                                          */
@@ -136,6 +143,8 @@ size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len);
 #define ST_DEC_EARLY_EXIT 1   /* stop a sentence at its first EOS/PAD token (output-equivalent:
                                  data.py:43-52 truncates there); off = the reference's fixed
                                  max_len-1 steps                                                 */
+#define ST_DEC_NO_SCREEN 2    /* f16x3 format: always run the 3-product generator (no one-product
+                                 screening pass; see gen_w_maxnorm)                              */
 
 /* ys = EncoderDecoder.greedy_decode(latent, max_len, start_id) (model.py:271-299) for B sentences.
  *   latent [B,256]   out_ids [B,max_len-1] int32 (positions after an early exit hold 0 = PAD)

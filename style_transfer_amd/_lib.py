@@ -11,6 +11,8 @@ ST_MAX_REFS = 16
 ST_ARGMAX_SPLITS = 4
 ST_F_NOT_NLL, ST_F_SIMPLEST, ST_F_JUST_USE_ONE = 1, 2, 4
 ST_DEC_EARLY_EXIT = 1
+ST_DEC_NO_SCREEN = 2
+ST_PROF_OFF, ST_PROF_GENERATOR, ST_PROF_HALF_LAYER = 0, 1, 2
 ST_GEMM_F32, ST_GEMM_F16X3 = 0, 1
 GEMM_FORMATS = {"f32": ST_GEMM_F32, "f16x3": ST_GEMM_F16X3}
 ABI_VERSION = 2
@@ -33,7 +35,7 @@ class StDecLayer(C.Structure):
 class StDecoderWeights(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
                 ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
-                ("gemm_format", C.c_int32), ("reserved0", C.c_int32),
+                ("gemm_format", C.c_int32), ("gen_w_maxnorm", C.c_float),
                 ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp), ("gen_w", fp), ("gen_b", fp),
                 ("layer", StDecLayer * ST_MAX_LAYERS)]
 

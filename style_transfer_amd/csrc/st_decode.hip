@@ -23,12 +23,13 @@ struct ProfPair {
   hipEvent_t a, b;
   double flops;
 };
-static bool g_prof_on = false;
+static int g_prof_on = 0;  // ST_PROF_*: which kernel's launches are bracketed
 static std::vector<ProfPair> g_prof;       // recorded pairs
 static std::vector<ProfPair> g_prof_free;  // recycled events
 
-extern "C" int st_profile_enable(int on) {
-  g_prof_on = on != 0;
+extern "C" int st_profile_enable(int which) {
+  ST_CHECK_ARG(which >= ST_PROF_OFF && which <= ST_PROF_HALF_LAYER, "st_profile_enable: which=%d", which);
+  g_prof_on = which;
   return ST_OK;
 }
 extern "C" int st_profile_read(double* gen_ms, double* gen_flops, long long* gen_launches, int reset) {
@@ -73,10 +74,14 @@ static int prof_end(ProfPair* p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
                                                     const int* __restrict__ idx, const int* __restrict__ n_dev,
-                                                    int* __restrict__ n_next, const int32_t* __restrict__ ys, int T,
-                                                    int pos, int bos, int vocab, float* __restrict__ x) {
+                                                    int* __restrict__ n_next, int* __restrict__ n_amb,
+                                                    const int32_t* __restrict__ ys, int T, int pos, int bos, int vocab,
+                                                    float* __restrict__ x) {
   const int n = *n_dev;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *n_next = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *n_next = 0;
+    *n_amb = 0;
+  }
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const int lane = threadIdx.x & 63;
@@ -192,26 +197,59 @@ __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // merge the generator's per-split (best, index, second) partials; emit the token; keep the sentence
 // live unless it produced EOS/PAD (early exit) or this was the last step.
+//   rows != null: partial row i belongs to live row rows[i] (the redo pass over ambiguous rows).
+//   margin_c >= 0: the partials come from the one-product screening pass; partial.w is the 2-norm of the
+//   row.  Every screened logit is within E = margin_c/2 * norm (+ slack) of its exact value, so the best
+//   column is certainly the exact argmax when it leads the runner-up by more than 2E; otherwise the row
+//   is appended to amb_idx and decided by the 3-product kernel.
 // ------------------------------------------------------------------------------------------------
+// slot in an append-only list for every lane with pred set: ONE atomic per wave (all 64 lanes must call)
+__device__ __forceinline__ int wave_append(int* counter, bool pred) {
+  const unsigned long long mask = __ballot(pred);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0 && mask) base = atomicAdd(counter, __popcll(mask));
+  base = __shfl(base, 0, 64);
+  return base + __popcll(mask & ((1ull << lane) - 1ull));
+}
+
 __global__ __launch_bounds__(256) void finish_kernel(const float4* __restrict__ partial, int nsplit,
                                                      const int* __restrict__ idx, const int* __restrict__ n_dev,
                                                      int32_t* __restrict__ ys, float* __restrict__ gap, int T, int pos,
                                                      int eos, int pad, int early, int last, int* __restrict__ idx_next,
-                                                     int* __restrict__ n_next) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= *n_dev) return;
-  float4 p0 = partial[(size_t)r * nsplit];
-  Top2 t = {p0.x, __float_as_int(p0.y), p0.z};
-  for (int k = 1; k < nsplit; ++k) {
-    const float4 pk = partial[(size_t)r * nsplit + k];
-    Top2 u = {pk.x, __float_as_int(pk.y), pk.z};
-    t = top2_merge(t, u);
+                                                     int* __restrict__ n_next, const int* __restrict__ rows,
+                                                     float margin_c, int* __restrict__ amb_idx, int* __restrict__ n_amb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < *n_dev;
+  Top2 t = {0.0f, 0, 0.0f};
+  float norm = 0.0f;
+  int r = 0;
+  if (valid) {
+    const float4 p0 = partial[(size_t)i * nsplit];
+    t.m1 = p0.x; t.i1 = __float_as_int(p0.y); t.m2 = p0.z;
+    norm = p0.w;
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 pk = partial[(size_t)i * nsplit + k];
+      Top2 u = {pk.x, __float_as_int(pk.y), pk.z};
+      t = top2_merge(t, u);
+    }
+    r = rows ? rows[i] : i;
   }
-  const int s = idx[r];
-  ys[(size_t)s * T + pos] = t.i1;
-  if (gap) gap[(size_t)s * T + pos] = t.m1 - t.m2;
-  const bool done = last || (early && (t.i1 == eos || t.i1 == pad));
-  if (!done) idx_next[atomicAdd(n_next, 1)] = s;
+  const bool amb = valid && margin_c >= 0.0f && !(t.m1 - t.m2 > margin_c * norm + 1e-4f);
+  if (margin_c >= 0.0f) {  // uniform
+    const int slot = wave_append(n_amb, amb);
+    if (amb) amb_idx[slot] = r;
+  }
+  const bool emit = valid && !amb;
+  int s = 0;
+  if (emit) {
+    s = idx[r];
+    ys[(size_t)s * T + pos] = t.i1;
+    if (gap) gap[(size_t)s * T + pos] = t.m1 - t.m2;
+  }
+  const bool live = emit && !(last || (early && (t.i1 == eos || t.i1 == pad)));
+  const int slot = wave_append(n_next, live);
+  if (live) idx_next[slot] = s;
 }
 
 __global__ void iota_kernel(int* idx, int* n_dev, int n) {
@@ -252,10 +290,13 @@ struct DecodeWs {
   float* cc;       // [L][B][256] cross-attention constants
   float4* partial; // [B][GEN_SPLITS]
   int* idx[2];     // [B]
-  int* cnt;        // [2]
+  int* amb;        // [B] live rows the screening pass could not decide
+  int* cnt;        // [0],[1]: live counts (ping-pong), [2]: ambiguous rows of the current step
   size_t total;
 };
-#define ST_GEN_SPLITS 16  /* max column splits of the generator (partials per row) */
+#define ST_GEN_SPLITS 16        /* max column splits of the generator (partials per row) */
+#define ST_SCREEN_MIN_ROWS 2048 /* below this the two extra launches of the screened argmax cost more than they save */
+#define ST_GEN_SPLITS_SMALL 96  /* ... when few rows are live: the late steps are latency-bound on streaming W */
 
 static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base) {
   DecodeWs ws;
@@ -272,9 +313,10 @@ static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base)
   ws.att = (float*)take((size_t)B * 256 * 4);
   ws.h = (float*)take((size_t)B * w->d_ff * 4);
   ws.cc = (float*)take((size_t)L * B * 256 * 4);
-  ws.partial = (float4*)take((size_t)B * ST_GEN_SPLITS * 16);
+  ws.partial = (float4*)take(((size_t)B * ST_GEN_SPLITS + ST_GEN_SPLITS_SMALL * 64) * 16);
   ws.idx[0] = (int*)take((size_t)B * 4);
   ws.idx[1] = (int*)take((size_t)B * 4);
+  ws.amb = (int*)take((size_t)B * 4);
   ws.cnt = (int*)take(256);
   ws.total = off;
   return ws;
@@ -340,6 +382,12 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     ST_TRY(launch_rp<EPI_BIAS>(g, B, 1, st));
   }
 
+  // Screened argmax (f16x3 only; not when the caller wants the exact top-2 gaps): every screened logit is
+  // within (2^-10 + 2^-16) * ||x|| * max_v ||W_v|| of the exact one (f16 rounding of both operands + f32
+  // accumulation); 25 % slack on top.  margin_c multiplies the row norm in finish_kernel.
+  const bool screen_ok = w->gemm_format == ST_GEMM_F16X3 && top2gap == nullptr && w->gen_w_maxnorm > 0.0f &&
+                         !(options & ST_DEC_NO_SCREEN);
+  const float margin_c = 2.0f * 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f) * w->gen_w_maxnorm;
   int n_bound = B;
   int cur = 0;
   int steps = 0;
@@ -349,7 +397,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     const int* idx = ws.idx[cur];
     const int* n_dev = ws.cnt + cur;
     hipLaunchKernelGGL(embed_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, w->emb, w->pe, idx, n_dev,
-                       ws.cnt + (cur ^ 1), out_ids, T, pos, bos, w->vocab, ws.x);
+                       ws.cnt + (cur ^ 1), ws.cnt + 2, out_ids, T, pos, bos, w->vocab, ws.x);
     ST_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
       const StDecLayer& y = w->layer[l];
@@ -360,7 +408,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
-      ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, rp_splits(n_bound, 768, 3, rp_nw(w->gemm_format, 8)), st)));
+      ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, rp_splits(n_bound, 768, n_bound <= 2048 ? 8 : 3, rp_nw(w->gemm_format, 8)), st)));
       if (pos < 16)
         hipLaunchKernelGGL(attn_step16_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
                            n_dev, pos, ws.att);
@@ -374,7 +422,11 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       of.cconst = ws.cc + (size_t)l * B * 256; of.idx = idx; of.ln_a = y.ln2_a; of.ln_b = y.ln2_b;
       of.w1 = y.w1; of.b1 = y.b1; of.h = ws.h; of.d_ff = w->d_ff; of.w2 = y.w2; of.b2 = y.b2;
       if (w->gemm_format == ST_GEMM_F16X3 && n_bound >= RP_TAIL_MIN_ROWS) {
+        ProfPair pt;
+        if (g_prof_on == ST_PROF_HALF_LAYER)
+          ST_TRY(prof_begin(&pt, 2.0 * (double)n_bound * 256.0 * (256.0 + 2.0 * (double)w->d_ff), st));
         ST_TRY(launch_layer_tail(of, n_bound, st));  // O-projection + FFN in one kernel
+        if (g_prof_on == ST_PROF_HALF_LAYER) ST_TRY(prof_end(&pt, st));
         continue;
       }
       if (n_bound >= RP_FUSE_MIN_ROWS) {
@@ -389,7 +441,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         f1.fmt = w->gemm_format;
         f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
         f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
-        ST_TRY((launch_rp<EPI_RELU, 8>(f1, n_bound, rp_splits(n_bound, w->d_ff, 4, rp_nw(w->gemm_format, 8)), st)));
+        ST_TRY((launch_rp<EPI_RELU, 8>(f1, n_bound, rp_splits(n_bound, w->d_ff, n_bound <= 2048 ? 8 : 4, rp_nw(w->gemm_format, 8)), st)));
       }
       GemmArgs f2 = {};
       f2.fmt = w->gemm_format;
@@ -401,15 +453,37 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     gg.fmt = w->gemm_format;
     gg.X = ws.x; gg.n_dev = n_dev; gg.n_host = n_bound; gg.ln_a = w->lnf_a; gg.ln_b = w->lnf_b;
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
+    // partial buffer: B * ST_GEN_SPLITS + 64 * ST_GEN_SPLITS_SMALL entries
+    const long room = ((long)B * ST_GEN_SPLITS + 64L * ST_GEN_SPLITS_SMALL) / n_bound;
+    const int gsplits = rp_splits(n_bound, w->vocab, (int)(room < ST_GEN_SPLITS_SMALL ? (room < ST_GEN_SPLITS ? ST_GEN_SPLITS : room) : ST_GEN_SPLITS_SMALL));
+    const int last = pos == T - 1 ? 1 : 0;
+    const bool screen = screen_ok && n_bound >= ST_SCREEN_MIN_ROWS;
     ProfPair pp;
-    if (g_prof_on) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
-    const int gsplits = rp_splits(n_bound, w->vocab, ST_GEN_SPLITS);
-    ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, gsplits, st));
-    if (g_prof_on) ST_TRY(prof_end(&pp, st));
-    hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx,
-                       n_dev, out_ids, top2gap, T, pos, eos, pad, early, pos == T - 1 ? 1 : 0, ws.idx[cur ^ 1],
-                       ws.cnt + (cur ^ 1));
-    ST_LAUNCH_CHECK();
+    if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
+    if (screen) {
+      // pass 1: one-product logits for every live row; rows with a clear winner are finished
+      ST_TRY(launch_rp_argmax_screen(gg, n_bound, gsplits, st));
+      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx, n_dev,
+                         out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
+                         (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2);
+      ST_LAUNCH_CHECK();
+      // pass 2: the undecided rows again with the 3-product kernel (row gather through ws.amb; the grid covers
+      // the worst case, workgroups beyond the ambiguous count exit at once)
+      gg.xrows = ws.amb; gg.n_dev = ws.cnt + 2;
+      const int rsplits = rp_splits((n_bound + 15) / 16, w->vocab, ST_GEN_SPLITS);
+      ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, rsplits, st));
+      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, rsplits, idx, ws.cnt + 2,
+                         out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
+                         (const int*)ws.amb, -1.0f, (int*)nullptr, (int*)nullptr);
+      ST_LAUNCH_CHECK();
+    } else {
+      ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, gsplits, st));
+      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx, n_dev,
+                         out_ids, top2gap, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
+                         (const int*)nullptr, -1.0f, (int*)nullptr, (int*)nullptr);
+      ST_LAUNCH_CHECK();
+    }
+    if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_end(&pp, st));
     cur ^= 1;
     ++steps;
     if (early && ((pos + 1) % sync_every == 0) && pos + 1 < T) {

@@ -51,6 +51,7 @@ struct GemmArgs {
   const float* lse;
   const float* g;
   int fmt;             // row-panel kernels: operand format of the packed W (ST_GEMM_F32 / ST_GEMM_F16X3)
+  const int* xrows;    // row-panel kernels: optional gather, panel row r reads X[xrows[r]] (null = X[r])
 };
 
 struct Lse {

@@ -46,17 +46,22 @@ __device__ __forceinline__ void panel_store4(float* row, int c4, f32x4 v) {
   }
 }
 
-template <int EPI, int NW = 4, bool H = false>
+// SCREEN (EPI_ARGMAX, H only): the cheap first pass of the screened argmax (st_decode.hip): ONE product per
+// term (hi.hi, no lo fragments are loaded) and the row's 2-norm in partial.w, from which the caller bounds
+// the error of these logits; rows whose top-2 gap is inside the bound are redone by the 3-product kernel.
+template <int EPI, int NW = 4, bool H = false, bool SCREEN = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;                  // [64][ST_LDA]
   float* red = smem + 64 * ST_LDA;   // [NW waves][64 rows][4]
+  float* rownorm = red + 4 * 64 * 4; // [64] (SCREEN; NW == 4 leaves the upper half of `red` free)
   const int n = a.n_dev ? *a.n_dev : a.n_host;
   const int m0 = blockIdx.x * 64;
   if (m0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the W address math on the scalar unit
   const int half = lane >> 5, l31 = lane & 31;
+  auto xrow = [&](int r) -> int { return a.xrows ? a.xrows[r] : r; };  // optional row gather (ARGMAX redo pass)
 
   // ---- X panel -> LDS (64 rows x 64 float4, 16 per thread), optional LayerNorm ----
   if (a.ln_a) {
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
     for (int i = 0; i < 64 / NW; ++i) {
       const int f = tid + i * 64 * NW;
       const int r = f >> 6, c4 = f & 63;
-      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)xrow(min(m0 + r, n - 1)) * 256 + c4 * 4);
     }
     __syncthreads();
     const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
@@ -72,15 +77,21 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
 #pragma unroll 4
     for (int rr = 0; rr < 64 / NW; ++rr) {
       float* row = As + (wave * (64 / NW) + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
-      panel_store4<H>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
+      const f32x4 y = layernorm256(*(f32x4*)(row + lane * 4), ga, gb);
+      if (SCREEN) {
+        const float ss = wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
+        if (lane == 0) rownorm[wave * (64 / NW) + rr] = sqrtf(ss);
+      }
+      panel_store4<H>(row, lane, y);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < 64 / NW; ++i) {
       const int f = tid + i * 64 * NW;
       const int r = f >> 6, c4 = f & 63;
-      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
+      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)xrow(min(m0 + r, n - 1)) * 256 + c4 * 4));
     }
+    if (SCREEN && tid < 64) rownorm[tid] = INFINITY;  // no norm available: every row counts as ambiguous
   }
   __syncthreads();
 
@@ -119,12 +130,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
     const int blk = b0 + wave + NW * (g / SPB);
     return H ? Wl[(((size_t)blk * SPB + (g & (SPB - 1))) * 2 + p) * 64] : Wl[((size_t)blk * SPB + (g & (SPB - 1))) * 64];
   };
-  f32x4 ring[R], ringl[H ? R : 1];
+  f32x4 ring[R], ringl[(H && !SCREEN) ? R : 1];
   if (total > 0) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       ring[j] = wload(j, 0);
-      if (H) ringl[j] = wload(j, 1);
+      if (H && !SCREEN) ringl[j] = wload(j, 1);
     }
   }
   const float* Ab = As + l31 * ST_LDA + 4 * half;
@@ -141,9 +152,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   f32x4 an[H ? 4 : 1];
   if (H) {
     an[0] = *(const f32x4*)(Ab);
-    an[1] = *(const f32x4*)(Ab + 128);
     an[2] = *(const f32x4*)(Ab + 32 * ST_LDA);
-    an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
+    if (!SCREEN) {
+      an[1] = *(const f32x4*)(Ab + 128);
+      an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
+    }
   }
   for (int g0 = 0; g0 < total; g0 += R) {
     if ((g0 & (SPB - 1)) == 0) bnext = bias_of(g0 / SPB + 1);
@@ -162,7 +175,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int kg = (g0 + j) & (SPB - 1);
-      if (H) {
+      if (H && SCREEN) {
+        const h8 bh = as_h8(ring[j]);
+        ring[j] = wload(g0 + j + R, 0);
+        const h8 a0h = as_h8(an[0]), a1h = as_h8(an[2]);
+        const int kn = (kg + 1) & (SPB - 1);
+        an[0] = *(const f32x4*)(Ab + kn * 8);
+        an[2] = *(const f32x4*)(Ab + 32 * ST_LDA + kn * 8);
+        acc0 = mfma16h(a0h, bh, acc0);
+        acc1 = mfma16h(a1h, bh, acc1);
+      } else if (H) {
         const h8 bh = as_h8(ring[j]), bl = as_h8(ringl[j]);
         ring[j] = wload(g0 + j + R, 0);
         ringl[j] = wload(g0 + j + R, 1);
@@ -296,7 +318,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
           Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
           t = top2_merge(t, u);
         }
-        a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, 0.0f);
+        a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] =
+            make_float4(t.m1, __int_as_float(t.i1), t.m2, SCREEN ? rownorm[tid] : 0.0f);
       } else {
         Lse t = {red[tid * 4 + 0], red[tid * 4 + 1]};
         float tg = red[tid * 4 + 2];
@@ -347,6 +370,18 @@ static int launch_rp_t(const GemmArgs& a, int n_bound, int splits, hipStream_t s
   if (n_bound <= 0) return ST_OK;
   dim3 grid((n_bound + 63) / 64, splits);
   hipLaunchKernelGGL((rp_gemm_kernel<EPI, NW, H>), grid, dim3(64 * NW), RP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+static int launch_rp_argmax_screen(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI_ARGMAX, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               RP_LDS));
+    attr_done = true;
+  }
+  if (n_bound <= 0) return ST_OK;
+  hipLaunchKernelGGL((rp_gemm_kernel<EPI_ARGMAX, 4, true, true>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

@@ -312,6 +312,30 @@ def test_large_batch_paths_equal_small_batch(dev, ae, ae_sd):
     assert int(same.sum().item()) >= len(sents) - 1, same.cpu().tolist()
 
 
+def test_screened_argmax_equals_full_product(dev, ae, gold_notnll):
+    """f16x3 format, >= 2048 live rows: the generator first runs a ONE-product (hi.hi) pass and redoes only the
+    rows whose top-2 gap is inside the error bound of that pass with the 3-product kernel.  The emitted ids
+    must equal those of the full product on every row (bit-exact integer work), on distinct latents."""
+    from style_transfer_amd import ops
+    if ae.gemm_format != "f16x3":
+        pytest.skip("the screening pass exists only in the f16x3 format")
+    rng = np.random.default_rng(5)
+    base = gold_notnll["latent"].reshape(-1, 256)                       # 1152 latents of real edit trajectories
+    lat = np.concatenate([base + rng.standard_normal(base.shape).astype(np.float32) * s for s in (0, 0.05, 0.1, 0.2, 0.4, 0.8)])
+    lat = torch.from_numpy(lat.astype(np.float32)).to(dev)              # 6912 distinct rows
+    ids_full, _, steps_full = ops.greedy_decode(ae, lat, screen=False)
+    ids_scr, _, steps_scr = ops.greedy_decode(ae, lat, screen=True)
+    assert steps_full == steps_scr
+    assert torch.equal(ids_full, ids_scr)
+    ids_fixed, _, _ = ops.greedy_decode(ae, lat, screen=True, early_exit=False)
+    ends = ((ids_full == 3) | (ids_full == 0)).int().argmax(dim=1)
+    has_end = ((ids_full == 3) | (ids_full == 0)).any(dim=1)
+    col = torch.arange(59, device=dev)[None]
+    upto = torch.where(has_end, ends, torch.full_like(ends, 58))[:, None]
+    assert torch.equal(torch.where(col <= upto, ids_fixed, torch.zeros_like(ids_fixed)),
+                       torch.where(col <= upto, ids_full, torch.zeros_like(ids_full)))
+
+
 def test_constraint_loss_wrapper_single_rank(dev):
     """contrastive.constraint_loss_and_grads on one rank with the HIP kernels == reference torch autograd"""
     from style_transfer_amd.contrastive import constraint_loss_and_grads
