@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16384, help="sentences per GPU per step")
+    ap.add_argument("--batch", type=int, default=32768, help="sentences per GPU per step (KV cache: 2.4 MB per sentence)")
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
     ap.add_argument("--tokens", default="zipf", choices=["zipf", "uniform", "real"],
                     help="synthetic token ids: unigram (Zipfian) from word_to_id.txt counts, uniform in [4,V), or the "
@@ -164,10 +164,12 @@ def main():
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
                        "iters_per_decode": cfg.iters_per_decode, "gemm_format": a.gemm_format,
                        "edit_iteration_units_per_s": world * units / dt},
-            # achieved = ALGORITHMIC flops (2*rows*256*V per launch) / kernel time.  f16x3 issues 3 MFMA flops per
+            # achieved = ALGORITHMIC flops of the timed kernel / its HIP-event time.  f16x3 issues 3 MFMA flops per
             # algorithmic flop, so frac <= 1/3 there by construction; mfma_issue_frac counts the issued ones.
-            "roofline": {"bound": "mfma", "kernel": "rp_gemm_kernel<EPI_ARGMAX,4,%s> (generator GEMM + fused argmax)"
-                                                    % ("true" if split else "false"),
+            "roofline": {"bound": "mfma",
+                         "kernel": ("rp_layer_tail_kernel (O-projection + residual + LayerNorm + FFN1 + FFN2 on one 64-row panel; "
+                                    "2*rows*256*(256+2*d_ff) flop per launch; largest share of GPU time in this format)") if split
+                                   else "rp_gemm_kernel<EPI_ARGMAX,4,false> (generator GEMM + fused argmax; 2*rows*256*V flop per launch)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
                          "mfma_flops_per_algorithmic_flop": 3 if split else 1,

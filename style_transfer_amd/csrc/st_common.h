@@ -33,10 +33,20 @@ void st_set_error(const char* fmt, ...);
 
 #define ST_LAUNCH_CHECK() ST_HIP(hipGetLastError())
 
+// Sum over the 64 lanes, result in every lane.  DPP row shifts + row broadcasts (6 VALU ops + one readlane)
+// instead of six ds_bpermute round trips through the LDS crossbar (~100 cycles each): the LayerNorm prologues
+// were spending most of their time there.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+#define ST_DPP_ADD(ctrl, row_mask)                                                                            \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, 0xf, false))
+  ST_DPP_ADD(0x111, 0xf);  // row_shr:1   (lanes shifted in from outside the 16-lane row read as 0)
+  ST_DPP_ADD(0x112, 0xf);  // row_shr:2
+  ST_DPP_ADD(0x114, 0xf);  // row_shr:4
+  ST_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row sum
+  ST_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  ST_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef ST_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

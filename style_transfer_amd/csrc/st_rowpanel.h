@@ -802,6 +802,12 @@ static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
   ACC0 = mfma16h(A0L, BH, ACC0);                             \
   ACC1 = mfma16h(A1L, BH, ACC1);
 
+#ifdef ST_TAIL_STAMPS
+__device__ unsigned long long g_tail_stamps[64];
+#define TSTAMP(i) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_tail_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(i)
+#endif
 template <int UNUSED = 0>
 __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -832,6 +838,15 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
     const int r = f >> 6, c4 = f & 63;
     panel_store4<true>(P1 + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
   }
+  // parameters used after barriers are fetched now (their latency would otherwise be exposed there)
+  const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+  const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+  const float b2v = a.b2[col];
+  f32x4 b1n[4];  // FFN1 bias of this lane's 16 hidden units in the coming chunk (transposed tile: 8g + 4*half + q)
+  auto b1_fetch = [&](int c) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b1n[g] = *(const f32x4*)(a.b1 + (c * 8 + wave) * 32 + 8 * g + 4 * half);
+  };
   // ---- O-projection; accumulators start from bias + residual (+ constant) ----
   const f32x4* Wo = (const f32x4*)a.wo + (size_t)wave * 16 * 128 + lane;
   ring_fill(Wo);
@@ -850,7 +865,9 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
       ax1[r] = v1;
     }
   }
+  TSTAMP(0);
   __syncthreads();
+  TSTAMP(1);
   const float* A1 = P1 + l31 * ST_LDA + 4 * half;  // fragment base in P1 (rows l31 and l31 + 32)
   const float* A2 = P2 + l31 * ST_LDA + 4 * half;
   // one 16-step pass: standard orientation (panel rows x W columns) or transposed (W rows x panel rows)
@@ -880,7 +897,10 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
     }
   };
   pass(A1, Wo, ax0, ax1, false);
+  TSTAMP(2);
+  b1_fetch(0);
   __syncthreads();  // every wave is done reading the attention panel
+  TSTAMP(3);
   // ---- x1 -> P1 (f32), LayerNorm + split in place ----
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -891,8 +911,6 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
   ring_fill(W1b);
   __syncthreads();
   {
-    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
-    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
 #pragma unroll 4
     for (int rr = 0; rr < 8; ++rr) {
       float* row = P1 + (wave * 8 + rr) * ST_LDA;
@@ -900,7 +918,6 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
     }
   }
   {
-    const float b2v = a.b2[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       ax0[r] += b2v;
@@ -909,17 +926,19 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
   }
   __syncthreads();
   _Float16* H2 = (_Float16*)P2;
+  TSTAMP(4);
   for (int c = 0; c < nchunk; ++c) {
     // ---- FFN1, hidden block jb = 8c + wave, transposed: lane = panel row, registers = hidden units ----
-    const int jb = c * 8 + wave;
     f32x16 ah0, ah1;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 bb = *(const f32x4*)(a.b1 + jb * 32 + 8 * g + 4 * half);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ah0[4 * g + q] = ah1[4 * g + q] = bb[q];
+      for (int q = 0; q < 4; ++q) ah0[4 * g + q] = ah1[4 * g + q] = b1n[g][q];
     }
+    if (c + 1 < nchunk) b1_fetch(c + 1);  // consumed one chunk later
+    TSTAMP(5 + c * 5);
     pass(A1, W1b, ah0, ah1, true);
+    TSTAMP(6 + c * 5);
     // next ring: this wave's W2 fragments for chunk c (k-steps 16c .. 16c+15 of output block `wave`)
     const f32x4* W2b = (const f32x4*)a.w2 + ((size_t)wave * (a.d_ff >> 4) + c * 16) * 128 + lane;
     ring_fill(W2b);
@@ -941,9 +960,12 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
       *(h4*)(H2 + (size_t)(32 + l31) * (2 * ST_LDA) + jl) = hi;
       *(h4*)(H2 + (size_t)(32 + l31) * (2 * ST_LDA) + 256 + jl) = lo;
     }
+    TSTAMP(7 + c * 5);
     __syncthreads();  // hidden chunk complete
+    TSTAMP(8 + c * 5);
     // ---- FFN2 partial: x += h_c . W2[:, chunk]^T ----
     pass(A2, W2b, ax0, ax1, false);
+    TSTAMP(9 + c * 5);
     if (c + 1 < nchunk) {
       W1b = (const f32x4*)a.w1 + (size_t)((c + 1) * 8 + wave) * 16 * 128 + lane;
       ring_fill(W1b);
@@ -955,6 +977,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
     if (row0 < n) ST_STORE(&a.x[(size_t)row0 * 256 + col], ax0[r]);
     if (row1 < n) ST_STORE(&a.x[(size_t)row1 * 256 + col], ax1[r]);
   }
+  TSTAMP(30);
 }
 
 static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) {

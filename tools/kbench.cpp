@@ -142,6 +142,17 @@ int main(int argc, char** argv) {
     a.w2 = w2_p; a.b2 = bias; a.d_ff = DFF;
     t = timeit([&] { launch_layer_tail(a, n, st); });
     printf("layer tail n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + 2 * DFF) / t / 1e12);
+#ifdef ST_TAIL_STAMPS
+    unsigned long long hs[64];
+    CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_tail_stamps), sizeof(hs)));
+    const char* nm[] = {"prologue issued", "barrier0", "O-proj", "barrier1", "x1->LDS + LN + barriers"};
+    for (int i = 1; i <= 4; ++i) printf("  %-28s %8llu\n", nm[i], hs[i] - hs[i - 1]);
+    for (int c = 0; c < 4; ++c) {
+      printf("  chunk %d: gap %6llu  PA %6llu  hwrite %6llu  barrier %6llu  PB %6llu\n", c, hs[5 + 5 * c] - (c ? hs[4 + 5 * c] : hs[4]),
+             hs[6 + 5 * c] - hs[5 + 5 * c], hs[7 + 5 * c] - hs[6 + 5 * c], hs[8 + 5 * c] - hs[7 + 5 * c], hs[9 + 5 * c] - hs[8 + 5 * c]);
+    }
+    printf("  epilogue %llu   total %llu (stamp 0 is after the prologue loads were issued)\n", hs[30] - hs[24], hs[30] - hs[0]);
+#endif
   }
 #ifdef HAVE_LAYER_FUSED
   {
