@@ -174,6 +174,7 @@ def main():
                          "frac": achieved / peak, "traffic": None,
                          "mfma_flops_per_algorithmic_flop": 3 if split else 1,
                          "mfma_issue_frac": achieved * (3 if split else 1) / peak,
+                         "achieved_over_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
                          "launches": int(gen_n.value), "avg_launch_us": gen_ms.value * 1e3 / max(1, gen_n.value),
                          "kernel_time_share": gen_ms.value * 1e-3 / dt},
         }

@@ -45,7 +45,8 @@ const char* st_last_error(void);
  * bracketed with an event pair; st_profile_read waits for them and returns the summed kernel
  * milliseconds, the summed algorithmic flops and the launch count; reset != 0 clears the record.
  *   ST_PROF_GENERATOR  : generator GEMM + argmax (both passes when screened); 2 * live_rows * 256 * V flops
- *   ST_PROF_HALF_LAYER : the fused post-attention half-layer (f16x3 format); 2 * live_rows * 256 * (256 + 2 d_ff)
+ *   ST_PROF_HALF_LAYER : the fused post-attention half-layer (f16x3 format) of st_decode_greedy AND
+ *                        st_encode_latent; 2 * rows * 256 * (256 + 2 d_ff)
  * (live_rows is exact when sync_every == 1).                                                      */
 #define ST_PROF_OFF 0
 #define ST_PROF_GENERATOR 1

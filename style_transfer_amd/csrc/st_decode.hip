@@ -19,11 +19,7 @@ extern "C" int st_abi_version(void) { return 2; }
 
 // ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
 #include <vector>
-struct ProfPair {
-  hipEvent_t a, b;
-  double flops;
-};
-static int g_prof_on = 0;  // ST_PROF_*: which kernel's launches are bracketed
+int g_prof_on = 0;  // ST_PROF_*: which kernel's launches are bracketed (also read by st_encode.hip)
 static std::vector<ProfPair> g_prof;       // recorded pairs
 static std::vector<ProfPair> g_prof_free;  // recycled events
 
@@ -50,7 +46,7 @@ extern "C" int st_profile_read(double* gen_ms, double* gen_flops, long long* gen
   }
   return ST_OK;
 }
-static int prof_begin(ProfPair* p, double flops, hipStream_t st) {
+int prof_begin(ProfPair* p, double flops, hipStream_t st) {
   if (!g_prof_free.empty()) {
     *p = g_prof_free.back();
     g_prof_free.pop_back();
@@ -62,7 +58,7 @@ static int prof_begin(ProfPair* p, double flops, hipStream_t st) {
   ST_HIP(hipEventRecord(p->a, st));
   return ST_OK;
 }
-static int prof_end(ProfPair* p, hipStream_t st) {
+int prof_end(ProfPair* p, hipStream_t st) {
   ST_HIP(hipEventRecord(p->b, st));
   g_prof.push_back(*p);
   return ST_OK;

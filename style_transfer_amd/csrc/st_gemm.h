@@ -226,6 +226,15 @@ static int launch_kloop(const GemmArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
+// in-library kernel timing (st_profile_enable / st_profile_read, defined in st_decode.hip)
+struct ProfPair {
+  hipEvent_t a, b;
+  double flops;
+};
+extern int g_prof_on;
+int prof_begin(ProfPair* p, double flops, hipStream_t st);
+int prof_end(ProfPair* p, hipStream_t st);
+
 #define ST_TRY(x)            \
   do {                       \
     int rc_ = (x);           \
