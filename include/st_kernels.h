@@ -104,11 +104,13 @@ int st_scorer_embed(const StScorerWeights* w, const float* x, float* z, int n, i
  *   unit vectors from st_scorer_embed(unit=1)     lr : [B] (pos_victim_lr / neg_victim_lr, :740)
  *   step : [B] Adam step count BEFORE this call (incremented here)   active : [B] 0 = skip row
  *   loss_out : [B] the value get_contrastive_loss returns (before the sign flip), may be NULL
- *   grad_out : [B,256] d(-loss)/d latent, may be NULL (parity tests)                              */
+ *   grad_out : [B,256] d(-loss)/d latent, may be NULL (parity tests)
+ *   scores_out : [B, n_pos + n_neg] the pos_score / neg_score values (cosine / tau, :410-418), may be NULL;
+ *   --dance prints a digest of them (:833-835)                                                     */
 int st_scorer_edit_step(const StScorerWeights* w, float* latent, float* adam_m, float* adam_v,
                         const float* like_z, const float* unlike_z, int n_pos, int n_neg,
                         const float* lr, int* step, const uint8_t* active, int B, float tau,
-                        int flags, float* loss_out, float* grad_out, void* stream);
+                        int flags, float* loss_out, float* grad_out, float* scores_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (2) Greedy decode with the Transformer autoencoder's decoder (KV-cached).

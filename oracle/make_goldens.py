@@ -233,6 +233,11 @@ if __name__ == "__main__":
         run_attack(sub, dict(task="amazon", not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "amazon", a.threads)
     elif a.what == "retext":
         run_attack([0, 1, 2, 3, 500, 501, 502, 503], dict(not_nll=True, retext=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "retext", a.threads)
+    elif a.what == "dance":
+        # --dance: two iterations, no Change lines, 'Siamese Loss score' / 'Siamese attack tensors' lines (:792-793, :833-835)
+        sub = [0, 1, 2, 3, 500, 501, 502, 503]
+        run_attack(sub, dict(dance=True, not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "dance_notnll", a.threads)
+        run_attack(sub, dict(dance=True), ckpt, "dance_nll", a.threads)
     elif a.what == "variants":
         sub = [0, 1, 2, 500, 501, 502]
         if not os.path.exists(os.path.join(GOLD, "attack_nll.npz")):

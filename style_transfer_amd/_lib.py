@@ -63,7 +63,7 @@ EXPORTS = {
     "st_pack_weight": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp]),
     "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
     "st_scorer_edit_step": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
-                                      C.c_int, C.c_float, C.c_int, fp, fp, fp]),
+                                      C.c_int, C.c_float, C.c_int, fp, fp, fp, fp]),
     "st_decode_workspace_bytes": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int, C.c_int]),
     "st_decode_greedy": (C.c_int, [C.POINTER(StDecoderWeights), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, fp, fp, fp, C.c_size_t, C.POINTER(C.c_int), fp]),

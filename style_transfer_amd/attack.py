@@ -73,6 +73,7 @@ class AttackResult:
     trace: dict = field(default_factory=dict)
     timing: dict = field(default_factory=dict)
     device: dict = None           # run_prepared(fetch=False): the same records as device tensors
+    dance: dict = None            # --dance: loss [S,I], scores [S,I,K+ + K-], n_pos, not_nll
 
 
 class AttackRunner:
@@ -175,6 +176,7 @@ class AttackRunner:
         want_gap = c.want_gap or c.want_trace
         tr = {k: [] for k in ("latent", "grad", "loss", "ids", "gap")} if c.want_trace else None
         max_change = (1 << 30) if c.dance else c.attack_max_change
+        dance_rec = []   # --dance: per iteration (loss [B], scores [B, kp + kn])
         C = 1 if c.retext else max(1, min(c.iters_per_decode, I))   # --retext: the latent itself depends on the decodes
         torch.cuda.synchronize(dev)
         tm["setup_s"] = time.perf_counter() - t0
@@ -192,10 +194,13 @@ class AttackRunner:
             cn = min(C, I - it0)
             snaps = [ori.index_select(0, live)] if it0 == 0 else []
             for j in range(cn):
-                loss, grad = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, active, tau=c.tau,
-                                                  not_nll=c.not_nll, simplest=c.simplest_siamese,
-                                                  just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
-                                                  want_grad=c.want_trace)
+                out = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, active, tau=c.tau,
+                                           not_nll=c.not_nll, simplest=c.simplest_siamese,
+                                           just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
+                                           want_grad=c.want_trace, want_scores=c.dance)
+                loss, grad = out[0], out[1]
+                if c.dance:
+                    dance_rec.append((loss.cpu().numpy(), out[2].cpu().numpy()))
                 snaps.append(ori.index_select(0, live))
                 if tr is not None:
                     tr["latent"].append(ori.detach().cpu().numpy().copy())
@@ -252,6 +257,9 @@ class AttackRunner:
         res.final_latent = final_latent.cpu().numpy()
         res.like_ids = None if like_ids_dev is None else like_ids_dev.cpu().numpy()
         res.unlike_ids = None if unlike_ids_dev is None else unlike_ids_dev.cpu().numpy()
+        if c.dance:
+            res.dance = dict(loss=np.stack([d[0] for d in dance_rec], 1), scores=np.stack([d[1] for d in dance_rec], 1),
+                             n_pos=kp, not_nll=c.not_nll)
         if tr is not None:
             res.trace = {k: np.stack(vv, 1) if vv else None for k, vv in tr.items()}
             res.trace["init_gap"] = None if init_gap is None else init_gap.cpu().numpy()
@@ -268,9 +276,21 @@ def concat_results(parts):
                      cat([p.changed for p in parts]), cat([p.like_ids for p in parts]), cat([p.unlike_ids for p in parts]),
                      cat([p.final_latent for p in parts]))
     r.timing = {k: sum(p.timing.get(k, 0) for p in parts) for k in ("setup_s", "loop_s", "units")}
+    if parts and getattr(parts[0], "dance", None):
+        r.dance = dict(parts[0].dance, loss=cat([p.dance["loss"] for p in parts]), scores=cat([p.dance["scores"] for p in parts]))
     if parts and parts[0].trace:
         r.trace = {k: cat([p.trace[k] for p in parts]) for k in parts[0].trace}
     return r
+
+
+def dance_digest(scores, n_pos, not_nll):
+    """The second value get_contrastive_loss returns (printed by --dance, siamese_contrastive.py:834):
+    --not_nll: #(pos_score > 0) + #(neg_score < 0) (:433); otherwise, per positive i, the argmax of
+    [pos_i, neg_0, ...] as a one-element list (:443-444)."""
+    pos, neg = scores[:n_pos], scores[n_pos:]
+    if not_nll:
+        return int((-pos < 0).sum() + (neg < 0).sum())
+    return [[int(np.argmax(np.concatenate([pos[i:i + 1], neg])))] for i in range(n_pos)]
 
 
 def write_attack_log(log, data: AttackSet, res: AttackResult, id_to_word, first_index=0, dance=False):
@@ -293,4 +313,9 @@ def write_attack_log(log, data: AttackSet, res: AttackResult, id_to_word, first_
             if res.changed[s, it] and not dance:
                 log("Change.{}, {}".format(k, text))
                 k += 1
+            if dance:
+                d = res.dance
+                # `loss = -(loss)` before the print (:806); .item() of an f32 tensor prints as a Python float
+                log("Siamese Loss score:{}".format(float(-np.float32(d["loss"][s, it]))))
+                log("Siamese attack tensors:{}".format(dance_digest(d["scores"][s, it], d["n_pos"], d["not_nll"])))
             log("iteration.{}, {}".format(it, text))

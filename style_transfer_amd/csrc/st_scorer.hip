@@ -86,6 +86,7 @@ struct ScorerArgs {
   int flags;
   float* loss_out;
   float* grad_out;
+  float* scores_out;  // [B, n_pos + n_neg] cos / tau (optional)
 };
 
 template <bool EDIT>
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void scorer_kernel(ScorerArgs a) {
         if (lane == 0) cosv[r * 32 + j] = d / pn;
       }
       __builtin_amdgcn_wave_barrier();
+      if (a.scores_out && lane < nt && m0 + r < n) a.scores_out[(size_t)(m0 + r) * nt + lane] = cosv[r * 32 + lane] * inv_tau;
       // per-lane coefficient g_j = d(-loss_ref)/d cos_j ; loss_ref = what get_contrastive_loss returns
       float g = 0.0f, lossv = 0.0f;
       if (a.flags & ST_F_NOT_NLL) {
@@ -298,7 +300,7 @@ extern "C" int st_scorer_embed(const StScorerWeights* w, const float* x, float* 
 extern "C" int st_scorer_edit_step(const StScorerWeights* w, float* latent, float* adam_m, float* adam_v,
                                    const float* like_z, const float* unlike_z, int n_pos, int n_neg, const float* lr,
                                    int* step, const uint8_t* active, int B, float tau, int flags, float* loss_out,
-                                   float* grad_out, void* stream) {
+                                   float* grad_out, float* scores_out, void* stream) {
   int rc = check_scorer(w);
   if (rc) return rc;
   ST_CHECK_ARG(B >= 0, "B=%d", B);
@@ -315,6 +317,6 @@ extern "C" int st_scorer_edit_step(const StScorerWeights* w, float* latent, floa
   ScorerArgs a = {};
   a.w = *w; a.n = B; a.latent = latent; a.adam_m = adam_m; a.adam_v = adam_v; a.like_z = like_z; a.unlike_z = unlike_z;
   a.n_pos = n_pos; a.n_neg = n_neg; a.lr = lr; a.step = step; a.active = active; a.tau = tau; a.flags = flags;
-  a.loss_out = loss_out; a.grad_out = grad_out;
+  a.loss_out = loss_out; a.grad_out = grad_out; a.scores_out = scores_out;
   return launch_scorer<true>(a, (hipStream_t)stream);
 }

@@ -93,7 +93,8 @@ def scorer_embed(sw, x, unit=True):
 
 
 def scorer_edit_step(sw, latent, adam_m, adam_v, like_z, unlike_z, lr, step, active, tau=0.1, not_nll=False,
-                     simplest=False, just_use_one=False, want_loss=False, want_grad=False):
+                     simplest=False, just_use_one=False, want_loss=False, want_grad=False, want_scores=False):
+    """-> (loss, grad), or (loss, grad, scores [B, n_pos + n_neg]) with want_scores."""
     B = latent.shape[0]
     _f32(latent, (B, 256)); _f32(adam_m, (B, 256)); _f32(adam_v, (B, 256)); _f32(lr, (B,))
     n_pos = 0 if like_z is None else like_z.shape[1]
@@ -108,11 +109,12 @@ def scorer_edit_step(sw, latent, adam_m, adam_v, like_z, unlike_z, lr, step, act
             (_lib.ST_F_JUST_USE_ONE if just_use_one else 0)
     loss = torch.empty(B, dtype=torch.float32, device=latent.device) if want_loss else None
     grad = torch.empty(B, 256, dtype=torch.float32, device=latent.device) if want_grad else None
+    scores = torch.empty(B, n_pos + n_neg, dtype=torch.float32, device=latent.device) if want_scores else None
     check(lib().st_scorer_edit_step(C.byref(sw.c), latent.data_ptr(), adam_m.data_ptr(), adam_v.data_ptr(),
                                     _p(like_z), _p(unlike_z), n_pos, n_neg, lr.data_ptr(), step.data_ptr(),
-                                    _p(active), B, float(tau), flags, _p(loss), _p(grad), _stream()),
+                                    _p(active), B, float(tau), flags, _p(loss), _p(grad), _p(scores), _stream()),
           "st_scorer_edit_step")
-    return loss, grad
+    return (loss, grad, scores) if want_scores else (loss, grad)
 
 
 def _fmt(gemm_format):

@@ -136,6 +136,38 @@ def test_log_is_byte_identical_to_reference(env, gold_notnll, tmp_path):
     assert sum(1 for x, y in zip(a, b) if x == y) >= S - 1
 
 
+@pytest.mark.parametrize("tag,flags", [
+    ("dance_notnll", dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2)),
+    ("dance_nll", dict()),
+])
+def test_dance_log_matches_reference(env, tag, flags, tmp_path):
+    """--dance (siamese_contrastive.py:792-793, :828-835): two iterations, no Change lines, and per iteration the
+    negated loss plus the digest of the scores (count of pos > 0 / neg < 0, or the argmax choice per positive).
+    The loss is printed with 16 digits: compared numerically (1e-4 relative); every other line must be identical."""
+    from style_transfer_amd.attack import write_attack_log
+    from style_transfer_amd.logfmt import LogWriter
+    g = gold("attack_%s.npz" % tag)
+    data, res = run(env, g, log_decodes=True, dance=True, **flags)
+    path = tmp_path / "log"
+    log = LogWriter(str(path), echo=False)
+    write_attack_log(log, data, res, env["id_to_word"], dance=True)
+    log.close()
+    mine = open(path).read().splitlines()
+    ref = open(os.path.join(GOLD, "attack_%s_log.txt" % tag)).read().splitlines()
+    ref = ref[next(i for i, l in enumerate(ref) if "Sentence Pair.0" in l):]
+    ref = [l for l in ref if l.split(" - ", 1)[1].strip("*")]   # the run's closing headline of asterisks
+    assert len(mine) == len(ref), (len(mine), len(ref))
+    n_loss = 0
+    for a, b in zip(mine, ref):
+        if "Siamese Loss score:" in b:
+            x, y = float(a.split("score:")[1]), float(b.split("score:")[1])
+            assert abs(x - y) <= 1e-4 * max(1.0, abs(y)), (a, b)
+            n_loss += 1
+        else:
+            assert a == b
+    assert n_loss == 2 * len(g["subset"]) and not any("Change." in l for l in mine)
+
+
 def test_cli_full_yelp_test_set_batch256(env, gold_notnll, tmp_path, capsys):
     """BASELINE config 2: the whole 1000-sentence yelp test split through the CLI at batch 256; the 64
     sentences that have reference goldens must come out identical, and every sentence must have an
