@@ -31,6 +31,8 @@ extern "C" {
 #define ST_EINVAL (-1)   /* bad argument / unsupported shape          */
 #define ST_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
 #define ST_ENOMEM (-3)   /* workspace too small                        */
+#define ST_ERANGE (-4)   /* f16x3 format: an activation left the f16 range (|x| >= 65504 or NaN); the
+                            outputs of that call are invalid — repack with ST_GEMM_F32             */
 
 #define ST_D 256          /* latent/model width the kernels are specialised for (main.py:70,73) */
 #define ST_MAX_LAYERS 4

@@ -364,13 +364,14 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
 
   ST_HIP(hipMemsetAsync(out_ids, 0, (size_t)B * T * 4, st));  // PAD after an early exit
   if (top2gap) ST_HIP(hipMemsetAsync(top2gap, 0, (size_t)B * T * 4, st));
+  ST_HIP(hipMemsetAsync(ws.cnt, 0, 256, st));  // counters and the f16-range flag (cnt[3])
   hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.idx[0], ws.cnt + 0, B);
   ST_LAUNCH_CHECK();
 
   // cross-attention constants: cc[l] = (latent Wv^T + bv) Wo^T + bo   (one key => softmax == 1)
   for (int l = 0; l < L; ++l) {
     GemmArgs g = {};
-    g.fmt = w->gemm_format;
+    g.fmt = w->gemm_format; g.range_flag = ws.cnt + 3;
     g.X = latent; g.n_host = B; g.W = w->layer[l].xv_w; g.bias = w->layer[l].xv_b; g.N = 256;
     g.out = ws.att; g.ldo = 256;
     ST_TRY(launch_rp<EPI_BIAS>(g, B, 1, st));
@@ -400,7 +401,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       float* kb = ws.kv + (size_t)(l * 2 + 0) * T * 256;
       float* vb = ws.kv + (size_t)(l * 2 + 1) * T * 256;
       GemmArgs g = {};
-      g.fmt = w->gemm_format;
+      g.fmt = w->gemm_format; g.range_flag = ws.cnt + 3;
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
@@ -413,7 +414,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
                            ws.att);
       ST_LAUNCH_CHECK();
       OFArgs of = {};
-      of.fmt = w->gemm_format;
+      of.fmt = w->gemm_format; of.range_flag = ws.cnt + 3;
       of.att = ws.att; of.n_dev = n_dev; of.n_host = n_bound; of.wo = y.wo; of.bo = y.bo; of.x = ws.x;
       of.cconst = ws.cc + (size_t)l * B * 256; of.idx = idx; of.ln_a = y.ln2_a; of.ln_b = y.ln2_b;
       of.w1 = y.w1; of.b1 = y.b1; of.h = ws.h; of.d_ff = w->d_ff; of.w2 = y.w2; of.b2 = y.b2;
@@ -429,24 +430,24 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         ST_TRY(launch_oproj_ffn1(of, n_bound, st));
       } else {
         GemmArgs o = {};
-        o.fmt = w->gemm_format;
+        o.fmt = w->gemm_format; o.range_flag = ws.cnt + 3;
         o.X = ws.att; o.n_dev = n_dev; o.n_host = n_bound; o.W = y.wo; o.bias = y.bo; o.N = 256;
         o.out = ws.x; o.ldo = 256; o.resid = ws.x; o.cconst = ws.cc + (size_t)l * B * 256; o.ld_cc = 256; o.idx = idx;
         ST_TRY(launch_rp<EPI_RESID>(o, n_bound, rp_splits(n_bound, 256, 2), st));
         GemmArgs f1 = {};
-        f1.fmt = w->gemm_format;
+        f1.fmt = w->gemm_format; f1.range_flag = ws.cnt + 3;
         f1.X = ws.x; f1.n_dev = n_dev; f1.n_host = n_bound; f1.ln_a = y.ln2_a; f1.ln_b = y.ln2_b;
         f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff; f1.out = ws.h; f1.ldo = w->d_ff;
         ST_TRY((launch_rp<EPI_RELU, 8>(f1, n_bound, rp_splits(n_bound, w->d_ff, n_bound <= 2048 ? 8 : 4, rp_nw(w->gemm_format, 8)), st)));
       }
       GemmArgs f2 = {};
-      f2.fmt = w->gemm_format;
+      f2.fmt = w->gemm_format; f2.range_flag = ws.cnt + 3;
       f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
       f2.out = ws.x; f2.ldo = 256; f2.resid = ws.x;
       ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, n_bound, st));
     }
     GemmArgs gg = {};
-    gg.fmt = w->gemm_format;
+    gg.fmt = w->gemm_format; gg.range_flag = ws.cnt + 3;
     gg.X = ws.x; gg.n_dev = n_dev; gg.n_host = n_bound; gg.ln_a = w->lnf_a; gg.ln_b = w->lnf_b;
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
     // partial buffer: B * ST_GEN_SPLITS + 64 * ST_GEN_SPLITS_SMALL entries
@@ -492,6 +493,16 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   }
   if (trace_steps) fprintf(stderr, "\n");
   if (n_steps_host) *n_steps_host = steps;
+  if (w->gemm_format == ST_GEMM_F16X3) {
+    int flag = 0;
+    ST_HIP(hipMemcpyAsync(&flag, ws.cnt + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+    ST_HIP(hipStreamSynchronize(st));
+    if (flag) {
+      st_set_error("st_decode_greedy: an activation left the f16 range (|x| >= 65504 or NaN) in the f16x3 format; "
+                   "the decoded ids are invalid - pack the weights with ST_GEMM_F32");
+      return ST_ERANGE;
+    }
+  }
   return ST_OK;
 }
 

@@ -132,7 +132,7 @@ extern "C" size_t st_encode_workspace_bytes(const StEncoderWeights* w, int n_row
   if (!w || n_rows <= 0) return 0;
   (void)n_sent;
   return enc_align((size_t)n_rows * 256 * 4) * 2 + enc_align((size_t)n_rows * 768 * 4) +
-         enc_align((size_t)n_rows * w->d_ff * 4);
+         enc_align((size_t)n_rows * w->d_ff * 4) + 256;  // + the f16-range flag
 }
 
 extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens, const int32_t* tok_pos,
@@ -162,7 +162,9 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
   float* x = (float*)base; base += enc_align((size_t)n_rows * 256 * 4);
   float* att = (float*)base; base += enc_align((size_t)n_rows * 256 * 4);
   float* qkv = (float*)base; base += enc_align((size_t)n_rows * 768 * 4);
-  float* h = (float*)base;
+  float* h = (float*)base; base += enc_align((size_t)n_rows * w->d_ff * 4);
+  int* range_flag = (int*)base;
+  ST_HIP(hipMemsetAsync(range_flag, 0, sizeof(int), st));
   const int R = n_rows;
   hipLaunchKernelGGL(enc_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->emb, w->pe, tokens, tok_pos, R, w->vocab, x);
   ST_LAUNCH_CHECK();
@@ -171,7 +173,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     ST_CHECK_ARG(y.ln0_a && y.ln0_b && y.wqkv && y.bqkv && y.wo && y.bo && y.ln1_a && y.ln1_b && y.w1 && y.b1 && y.w2 && y.b2,
                  "NULL weight pointer in encoder layer %d", l);
     GemmArgs g = {};
-    g.fmt = w->gemm_format;
+    g.fmt = w->gemm_format; g.range_flag = range_flag;
     g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
     g.out = qkv; g.ldo = 768;
     ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, rp_splits(R, 768, 3, rp_nw(w->gemm_format, 8)), st)));
@@ -179,7 +181,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     if (max_sent_len > 16) hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
     ST_LAUNCH_CHECK();
     OFArgs of = {};
-    of.fmt = w->gemm_format;
+    of.fmt = w->gemm_format; of.range_flag = range_flag;
     of.att = att; of.n_host = R; of.wo = y.wo; of.bo = y.bo; of.x = x; of.ln_a = y.ln1_a; of.ln_b = y.ln1_b;
     of.w1 = y.w1; of.b1 = y.b1; of.h = h; of.d_ff = w->d_ff; of.w2 = y.w2; of.b2 = y.b2;
     if (w->gemm_format == ST_GEMM_F16X3 && R >= RP_TAIL_MIN_ROWS) {
@@ -193,21 +195,31 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       ST_TRY(launch_oproj_ffn1(of, R, st));
     } else {
       GemmArgs o = {};
-      o.fmt = w->gemm_format;
+      o.fmt = w->gemm_format; o.range_flag = range_flag;
       o.X = att; o.n_host = R; o.W = y.wo; o.bias = y.bo; o.N = 256; o.out = x; o.ldo = 256; o.resid = x;
       ST_TRY(launch_rp<EPI_RESID>(o, R, rp_splits(R, 256, 2), st));
       GemmArgs f1 = {};
-      f1.fmt = w->gemm_format;
+      f1.fmt = w->gemm_format; f1.range_flag = range_flag;
       f1.X = x; f1.n_host = R; f1.ln_a = y.ln1_a; f1.ln_b = y.ln1_b; f1.W = y.w1; f1.bias = y.b1; f1.N = w->d_ff;
       f1.out = h; f1.ldo = w->d_ff;
       ST_TRY((launch_rp<EPI_RELU, 8>(f1, R, rp_splits(R, w->d_ff, 4, rp_nw(w->gemm_format, 8)), st)));
     }
     GemmArgs f2 = {};
-    f2.fmt = w->gemm_format;
+    f2.fmt = w->gemm_format; f2.range_flag = range_flag;
     f2.X = h; f2.n_host = R; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256; f2.out = x; f2.ldo = 256; f2.resid = x;
     ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, R, st));
   }
   hipLaunchKernelGGL(enc_latent_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, x, sent_off, n_sent, w->lnf_a, w->lnf_b, latent);
   ST_LAUNCH_CHECK();
+  if (w->gemm_format == ST_GEMM_F16X3) {  // the only synchronisation of this entry point, and only in this format
+    int flag = 0;
+    ST_HIP(hipMemcpyAsync(&flag, range_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    ST_HIP(hipStreamSynchronize(st));
+    if (flag) {
+      st_set_error("st_encode_latent: an activation left the f16 range (|x| >= 65504 or NaN) in the f16x3 format; "
+                   "the latents are invalid - pack the weights with ST_GEMM_F32");
+      return ST_ERANGE;
+    }
+  }
   return ST_OK;
 }

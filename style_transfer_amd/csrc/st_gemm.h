@@ -52,6 +52,7 @@ struct GemmArgs {
   const float* g;
   int fmt;             // row-panel kernels: operand format of the packed W (ST_GEMM_F32 / ST_GEMM_F16X3)
   const int* xrows;    // row-panel kernels: optional gather, panel row r reads X[xrows[r]] (null = X[r])
+  int* range_flag;     // f16x3: set to 1 when an activation leaves the f16 range (null = unchecked)
 };
 
 struct Lse {

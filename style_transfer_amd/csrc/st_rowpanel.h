@@ -32,10 +32,14 @@
 
 #define RP_LDS ((64 * ST_LDA + 8 * 64 * 4) * 4)
 
-// store 4 consecutive features of a panel row (feature index c = 4*c4) in the kernel's operand format
+// store 4 consecutive features of a panel row (feature index c = 4*c4) in the kernel's operand format.
+// f16x3: a value outside the f16 range (or NaN) would turn into inf - inf = NaN inside the products and come
+// out as a silent garbage argmax, so it raises *flag instead (checked by the host entry point: ST_ERANGE).
 template <bool H>
-__device__ __forceinline__ void panel_store4(float* row, int c4, f32x4 v) {
+__device__ __forceinline__ void panel_store4(float* row, int c4, f32x4 v, int* flag) {
   if (H) {
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (flag && !(m <= 65504.0f)) *flag = 1;
     h4 hi, lo;
     split_f16(v, hi, lo);
     _Float16* ph = (_Float16*)row;
@@ -82,14 +86,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
         const float ss = wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
         if (lane == 0) rownorm[wave * (64 / NW) + rr] = sqrtf(ss);
       }
-      panel_store4<H>(row, lane, y);
+      panel_store4<H>(row, lane, y, a.range_flag);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < 64 / NW; ++i) {
       const int f = tid + i * 64 * NW;
       const int r = f >> 6, c4 = f & 63;
-      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)xrow(min(m0 + r, n - 1)) * 256 + c4 * 4));
+      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)xrow(min(m0 + r, n - 1)) * 256 + c4 * 4), a.range_flag);
     }
     if (SCREEN && tid < 64) rownorm[tid] = INFINITY;  // no norm available: every row counts as ambiguous
   }
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
     for (int i = 0; i < 16; ++i) {
       const int f = tid + i * 256;
       const int r = f >> 6, c4 = f & 63;
-      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * K + c * 256 + c4 * 4));
+      panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * K + c * 256 + c4 * 4), a.range_flag);
     }
     __syncthreads();
     for (int g0 = 0; g0 < SPC; g0 += 4) {
@@ -571,6 +575,7 @@ struct OFArgs {
   int d_ff;
   int fmt;                       // operand format of wo / w1 / w2 (ST_GEMM_F32 / ST_GEMM_F16X3)
   const float *w2, *b2;          // packed [256,d_ff], [256]   (rp_layer_tail_kernel only)
+  int* range_flag;               // f16x3: set to 1 when an operand leaves the f16 range (null = unchecked)
 };
 
 template <bool H = false>
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
   for (int i = 0; i < 16; ++i) {
     const int f = tid + i * 256;
     const int r = f >> 6, c4 = f & 63;
-    panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
+    panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4), a.range_flag);
   }
   // ---- phase 1: O-projection, accumulators start from bias + residual (+ constant) ----
   const f32x4* W0 = (const f32x4*)a.wo + (size_t)wave * SPB * F * 64 + lane;
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
 #pragma unroll 4
     for (int rr = 0; rr < 16; ++rr) {
       float* row = As + (wave * 16 + rr) * ST_LDA;
-      panel_store4<H>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
+      panel_store4<H>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb), a.range_flag);
     }
   }
   __syncthreads();
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
   for (int i = 0; i < 8; ++i) {
     const int f = tid + i * 512;
     const int r = f >> 6, c4 = f & 63;
-    panel_store4<true>(P1 + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
+    panel_store4<true>(P1 + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4), a.range_flag);
   }
   // parameters used after barriers are fetched now (their latency would otherwise be exposed there)
   const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
 #pragma unroll 4
     for (int rr = 0; rr < 8; ++rr) {
       float* row = P1 + (wave * 8 + rr) * ST_LDA;
-      panel_store4<true>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
+      panel_store4<true>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb), a.range_flag);
     }
   }
   {
@@ -953,6 +958,10 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
       }
       h4 hi, lo;
       const int jl = wave * 32 + 8 * g + 4 * half;
+      {
+        const float mx = fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)));
+        if (a.range_flag && !(mx <= 65504.0f)) *a.range_flag = 1;  // hidden unit outside the f16 range (or NaN)
+      }
       split_f16(v0, hi, lo);
       *(h4*)(H2 + (size_t)l31 * (2 * ST_LDA) + jl) = hi;
       *(h4*)(H2 + (size_t)l31 * (2 * ST_LDA) + 256 + jl) = lo;

@@ -289,6 +289,31 @@ def test_errors_are_reported_not_thrown_across_abi(dev, ae):
         ops.greedy_decode(ae, torch.zeros(2, 256, device=dev), max_len=100)
 
 
+@pytest.mark.parametrize("n_rows", [48, 6000])   # small: unfused kernels; large: half-layer kernel
+def test_f16_range_violation_is_reported(dev, ae_sd_torch, n_rows):
+    """The f16x3 format needs every multiplied activation inside the f16 range.  A checkpoint that breaks this
+    (here: feed_forward.w_1 of one layer scaled by 3e4 -> hidden units ~1e6) must raise ST_ERANGE instead of
+    decoding garbage from inf - inf; the f32 format takes the same weights without complaint."""
+    from style_transfer_amd import ops, _lib
+    from style_transfer_amd.weights import AEWeights
+    from style_transfer_amd.data import pack_sentences
+    sd = {k: v.clone() for k, v in ae_sd_torch.items()}
+    sd["decoder.layers.1.feed_forward.w_1.weight"] *= 3e4
+    sd["encoder.layers.0.feed_forward.w_1.weight"] *= 3e4
+    lat = torch.rand(n_rows, 256, device=dev) * 8
+    bad = AEWeights(sd, dev, gemm_format="f16x3")
+    with pytest.raises(_lib.StError, match="f16 range"):
+        ops.greedy_decode(bad, lat)
+    sents = some_sentences(40, seed=3) * (1 + n_rows // 100)
+    tok, pos, off, mx = pack_sentences(sents)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    with pytest.raises(_lib.StError, match="f16 range"):
+        ops.encode_latent(bad, t(tok), t(pos), t(off), len(sents), mx)
+    ok = AEWeights(sd, dev, gemm_format="f32")
+    ids, _, _ = ops.greedy_decode(ok, lat)
+    assert ids.shape == (n_rows, 59)
+
+
 def test_large_batch_paths_equal_small_batch(dev, ae, ae_sd):
     """Full-size property: above 65536 rows the decoder / encoder switch to the fused O-projection+FFN1
     kernel and multi-round grids; every replica of a sentence must produce exactly the ids / (nearly) the
