@@ -139,54 +139,62 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
 }
 
 
-// Short-prefix variant (pos < 16, i.e. almost every step of a yelp decode): ONE wave per row handles all
-// four heads, lane = (head h = lane>>4, key j = lane&15), so all 64 lanes work in the score/softmax
-// phase (the general kernel above keeps 64-pos-1 lanes idle); in the PV phase lane owns output dims
-// 4*lane..4*lane+3, which belong to head lane>>4 again.
+// Short-prefix variant (pos < 16, i.e. almost every step of a yelp decode): ONE wave per row handles all four
+// heads.  Every K and V row is read as one coalesced 1 KiB wave load (lane l holds dims 4l..4l+3, which belong
+// to head l >> 4); q.k partial sums are reduced over the 16 lanes of a head with DPP row shifts, so every lane
+// of a head ends up with all of that head's scores and the softmax needs no further lane traffic; the PV sum
+// is lane-local.  All 2(pos+1) loads of a row are independent and issued up front.
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in all 16
+#define ST_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+  ST_ROW_ADD(0x121);  // row_ror:1
+  ST_ROW_ADD(0x122);  // row_ror:2
+  ST_ROW_ADD(0x124);  // row_ror:4
+  ST_ROW_ADD(0x128);  // row_ror:8
+#undef ST_ROW_ADD
+  return v;
+}
+
 __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
                                                           const float* __restrict__ vbase, long kv_stride,
                                                           const int* __restrict__ idx, const int* __restrict__ n_dev,
                                                           int pos, float* __restrict__ out) {
-  __shared__ __align__(16) float qs[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= *n_dev) return;
-  const int h = lane >> 4, j = lane & 15;
-  *(f32x4*)(&qs[wave][lane * 4]) = *(const f32x4*)(q + (size_t)r * 256 + lane * 4);
-  __builtin_amdgcn_wave_barrier();
   const long s = idx[r];
-  const float* K = kbase + s * kv_stride;
-  const float* V = vbase + s * kv_stride;
-  float sc = -INFINITY;
-  if (j <= pos) {
-    const float* kr = K + (size_t)j * 256 + h * 64;
-    float acc = 0.0f;
+  const float* K = kbase + s * kv_stride + lane * 4;
+  const float* V = vbase + s * kv_stride + lane * 4;
+  const f32x4 qv = *(const f32x4*)(q + (size_t)r * 256 + lane * 4);
+  f32x4 kr[16], vr[16];
 #pragma unroll
-    for (int d = 0; d < 64; d += 4) {
-      const f32x4 kv = *(const f32x4*)(kr + d);
-      const f32x4 qv = *(const f32x4*)(&qs[wave][h * 64 + d]);
-      acc = fmaf(qv.x, kv.x, acc);
-      acc = fmaf(qv.y, kv.y, acc);
-      acc = fmaf(qv.z, kv.z, acc);
-      acc = fmaf(qv.w, kv.w, acc);
+  for (int j = 0; j < 16; ++j)
+    if (j <= pos) {  // uniform
+      kr[j] = *(const f32x4*)(K + (size_t)j * 256);
+      vr[j] = *(const f32x4*)(V + (size_t)j * 256);
     }
-    sc = acc * 0.125f;
+  float sc[16];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sc[j] = -INFINITY;
+    if (j <= pos) {
+      const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
+      sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
+      m = fmaxf(m, sc[j]);
+    }
   }
-  float m = sc;
+  float sum = 0.0f;
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  const float e = j <= pos ? expf(sc - m) : 0.0f;
-  float sum = e;
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-  const float p = e / sum;
+  for (int j = 0; j < 16; ++j)
+    if (j <= pos) {
+      sc[j] = expf(sc[j] - m);
+      sum += sc[j];
+    }
+  const float inv = 1.0f / sum;
   f32x4 o4 = {0, 0, 0, 0};
-  const int base = lane & 48;
-  for (int jj = 0; jj <= pos; ++jj) {
-    const float pj = __shfl(p, base + jj, 64);
-    const f32x4 v4 = *(const f32x4*)(V + (size_t)jj * 256 + lane * 4);
-    o4 += pj * v4;
-  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j <= pos) o4 += (sc[j] * inv) * vr[j];
   *(f32x4*)(out + (size_t)r * 256 + lane * 4) = o4;
 }
 

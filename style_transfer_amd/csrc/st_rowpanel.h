@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   // accumulators start from the column's bias (fetched one block ahead) instead of zero
   auto bias_of = [&](int i) -> float {
     const int col = ((b0 + wave + NW * i) << 5) + l31;
+    if (EPI == EPI_ARGMAX && col >= a.N) return -INFINITY;  // padding columns of the last block never win
     return (a.bias && col < a.N) ? a.bias[col] : 0.0f;
   };
   float bnext = cnt > 0 ? bias_of(0) : 0.0f;
@@ -229,14 +230,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
           const int row = m0 + mi * 32 + mfma32_row(r, lane);
           float v = acc[r];
           if (EPI == EPI_ARGMAX) {
-            v = colok ? v : -INFINITY;
+            // columns >= N start from a -inf bias (bias_of), so they never win; 4 VALU ops per logit:
+            // second = median(best, v, second) because second <= best always holds
             Top2& t = best[mi][r];
-            const bool gt = v > t.m1;
-#ifndef ST_ABL_NOGAP
-            t.m2 = gt ? t.m1 : fmaxf(t.m2, v);
-#endif
-            t.i1 = gt ? col : t.i1;
-            t.m1 = gt ? v : t.m1;
+            t.i1 = v > t.m1 ? col : t.i1;
+            t.m2 = __builtin_amdgcn_fmed3f(t.m1, v, t.m2);
+            t.m1 = fmaxf(t.m1, v);
           } else if (EPI == EPI_LSE) {
             if (colok) {
               const float sv = v * a.scale;

@@ -59,7 +59,7 @@ static double timeit(F f, int iters = 10) {
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 65536;
   g_fmt = argc > 3 ? atoi(argv[3]) : ST_GEMM_F32;  // kbench <rows> <generator splits, 0 = auto> <format>
-  const char* only = argc > 4 ? argv[4] : "gfqo2ut";  // which kernels: g f q o 2 u
+  const char* only = argc > 4 ? argv[4] : "gsfqo2ut";  // which kernels: g f q o 2 u
   auto want = [&](char c) { return strchr(only, c) != nullptr; };
   printf("gemm_format %d\n", g_fmt);
   const int V = 9339, DFF = 1024;
@@ -91,6 +91,14 @@ int main(int argc, char** argv) {
     const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(n, V, 16);
     t = timeit([&] { launch_rp<EPI_ARGMAX>(g, n, sp, st); });
     printf("generator  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
+  }
+  if (want('s') && g_fmt == ST_GEMM_F16X3) {  // generator screening pass (one product)
+    GemmArgs g = {};
+    g.fmt = g_fmt;
+    g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
+    const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(n, V, 16);
+    t = timeit([&] { launch_rp_argmax_screen(g, n, sp, st); });
+    printf("gen screen n=%d splits=%d: %8.1f us %6.1f TF (one product)\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
   }
   if (want('f')) {  // FFN1 (rp RELU)
     GemmArgs g = {};
