@@ -57,9 +57,20 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
   }
 }
 
-// Sentences of <= 16 tokens (all of yelp): ONE wave per sentence handles the four heads, lane = (head
-// lane>>4, key lane&15); K and V slices of the sentence stay in registers for all its queries; in the PV
-// phase lane owns output dims 4*lane..4*lane+3 (head lane>>4 again).
+// Sentences of <= 16 tokens (all of yelp): ONE wave per sentence handles the four heads.  Lane l holds dims
+// 4l..4l+3 (head l >> 4) of every K and V row of the sentence in registers (coalesced 1 KiB row loads); for each
+// query the q.k partial sums are reduced over the 16 lanes of a head with DPP row rotations, so the softmax and
+// the PV sum need no further lane traffic (same scheme as attn_step16_kernel in st_decode.hip).
+__device__ __forceinline__ float enc_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in all 16
+#define ST_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+  ST_ROW_ADD(0x121);  // row_ror:1
+  ST_ROW_ADD(0x122);  // row_ror:2
+  ST_ROW_ADD(0x124);  // row_ror:4
+  ST_ROW_ADD(0x128);  // row_ror:8
+#undef ST_ROW_ADD
+  return v;
+}
+
 __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
                                                          int n_sent, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -67,42 +78,41 @@ __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict
   if (s >= n_sent) return;
   const int r0 = off[s], len = off[s + 1] - r0;
   if (len <= 0 || len > 16) return;
-  const int h = lane >> 4, j = lane & 15, base = lane & 48;
-  f32x4 kreg[16], vreg[16];
-  {
-    const float* kr = qkv + (size_t)(r0 + min(j, len - 1)) * 768 + 256 + h * 64;
+  const float* base = qkv + (size_t)r0 * 768 + lane * 4;
+  f32x4 kr[16], vr[16];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) kreg[d] = *(const f32x4*)(kr + d * 4);
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj)
-      vreg[jj] = *(const f32x4*)(qkv + (size_t)(r0 + min(jj, len - 1)) * 768 + 512 + lane * 4);
-  }
-  for (int i = 0; i < len; ++i) {
-    const float* qr = qkv + (size_t)(r0 + i) * 768 + h * 64;
-    float acc = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-      const f32x4 qv = *(const f32x4*)(qr + d * 4);
-      acc = fmaf(qv.x, kreg[d].x, acc);
-      acc = fmaf(qv.y, kreg[d].y, acc);
-      acc = fmaf(qv.z, kreg[d].z, acc);
-      acc = fmaf(qv.w, kreg[d].w, acc);
+  for (int j = 0; j < 16; ++j)
+    if (j < len) {  // uniform
+      kr[j] = *(const f32x4*)(base + (size_t)j * 768 + 256);
+      vr[j] = *(const f32x4*)(base + (size_t)j * 768 + 512);
     }
-    const float sc = j < len ? acc * 0.125f : -INFINITY;
-    float m = sc;
+  f32x4 qn = *(const f32x4*)base;
+  for (int i = 0; i < len; ++i) {
+    const f32x4 qv = qn;
+    if (i + 1 < len) qn = *(const f32x4*)(base + (size_t)(i + 1) * 768);
+    float sc[16];
+    float m = -INFINITY;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    const float e = j < len ? expf(sc - m) : 0.0f;
-    float sum = e;
+    for (int j = 0; j < 16; ++j) {
+      sc[j] = -INFINITY;
+      if (j < len) {
+        const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
+        sc[j] = enc_row16_sum(part) * 0.125f;  // / sqrt(d_k)
+        m = fmaxf(m, sc[j]);
+      }
+    }
+    float sum = 0.0f;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const float p = e / sum;
+    for (int j = 0; j < 16; ++j)
+      if (j < len) {
+        sc[j] = expf(sc[j] - m);
+        sum += sc[j];
+      }
+    const float inv = 1.0f / sum;
     f32x4 o4 = {0, 0, 0, 0};
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const float pj = __shfl(p, base + jj, 64);  // exactly 0 for jj >= len
-      o4 += pj * vreg[jj];
-    }
+    for (int j = 0; j < 16; ++j)
+      if (j < len) o4 += (sc[j] * inv) * vr[j];
     *(f32x4*)(out + (size_t)(r0 + i) * 256 + lane * 4) = o4;
   }
 }

@@ -198,3 +198,14 @@ def test_two_rank_global_negatives_loss_matches_reference(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_dance_digest_matches_reference_definition():
+    """--dance prints the second value of get_contrastive_loss (siamese_contrastive.py:433, :443-444)."""
+    from style_transfer_amd.attack import dance_digest
+    scores = np.array([0.5, -0.2, 0.1, 3.0, -1.0, 0.2], np.float32)   # 3 pos, 3 neg
+    # --not_nll: #(pos_loss < 0) + #(neg_loss < 0) with pos_loss = -pos_score, neg_loss = neg_score
+    assert dance_digest(scores, 3, True) == 2 + 1
+    # NLL: per positive i the argmax of [pos_i, neg_0, neg_1, neg_2]
+    assert dance_digest(scores, 3, False) == [[1], [1], [1]]
+    assert dance_digest(np.array([5.0, 0.0, 1.0, 2.0], np.float32), 1, False) == [[0]]
