@@ -283,6 +283,39 @@ def test_simloss_vs_oracle(dev, Bq, Bk, off):
     assert relerr(dl.cpu().numpy(), dl_ref) < 1e-3
 
 
+def test_simloss_full_size_b8192(dev):
+    """BASELINE config 5 at its full size (B = 8192 rows x 8192 in-batch negatives): the [B,B] matrix is never
+    materialised by the kernels; checked against a chunked float64 torch evaluation of the same formula
+    (siamese_contrastive.py:1060-1069) and through the size-independent identities sum_j dS[i,j] = 0
+    (=> d_ori is orthogonal to ori after the cosine Jacobian) and loss >= 0."""
+    from style_transfer_amd import ops
+    B, tau = 8192, 0.1
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    ori = (torch.rand(B, 256, generator=g) * 10).to(dev)
+    like = (torch.rand(B, 256, generator=g) * 10).to(dev)
+    like += 0.3 * ori
+    gw = torch.rand(B, generator=g).to(dev)
+    loss, lse = ops.simloss_fwd(ori, like, tau, 0)
+    d_ori, d_like = ops.simloss_bwd(ori, like, lse, gw, tau, 0)
+    o64 = ori.double().requires_grad_(True)
+    l64 = like.double().requires_grad_(True)
+    ou = o64 / o64.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    lu = l64 / l64.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    rows = []
+    for c in range(0, B, 1024):                      # 1024 x 8192 float64 blocks
+        sim = ou[c:c + 1024] @ lu.t() / tau
+        rows.append(torch.logsumexp(sim, 1) - sim[torch.arange(sim.shape[0]), torch.arange(c, c + sim.shape[0])])
+    ref = torch.cat(rows)
+    (ref * gw.double()).sum().backward()
+    assert float((loss.double() - ref.detach()).abs().max()) < 3e-4
+    assert float(loss.min()) >= 0.0
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    assert rel(d_ori, o64.grad) < 1e-3 and rel(d_like, l64.grad) < 1e-3
+    # cosine similarity is scale-invariant in each argument: every gradient row is orthogonal to its input row
+    assert float(((d_ori * ori).sum(1).abs() / (d_ori.norm(dim=1) * ori.norm(dim=1) + 1e-30)).max()) < 1e-3
+    assert float(((d_like * like).sum(1).abs() / (d_like.norm(dim=1) * like.norm(dim=1) + 1e-30)).max()) < 1e-3
+
+
 def test_errors_are_reported_not_thrown_across_abi(dev, ae):
     from style_transfer_amd import ops, _lib
     with pytest.raises(_lib.StError, match="max_len"):
