@@ -12,6 +12,8 @@
 
 #define SC_LD 516        // activation row stride in floats (512 + 4; = 4 mod 64 -> conflict-free b128)
 #define SC_ROWS 32
+#define SC_NW 8          // waves per workgroup: LDS allows one workgroup per CU, so 8 waves = 2 per SIMD
+#define SC_RPW (SC_ROWS / SC_NW)  // rows per wave in the row-wise phases
 #define SC_BUF (SC_ROWS * SC_LD)
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
@@ -24,9 +26,9 @@ template <int K, int N, bool FWD, int ACT>
 __device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float* __restrict__ Ys,
                                             const float* __restrict__ W, const float* __restrict__ bias,
                                             uint32_t* __restrict__ bits, int bits_ld) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  for (int c = wave; c < N / 32; c += 4) {
+  for (int c = wave; c < N / 32; c += SC_NW) {
     f32x16 acc = {0};
     const float* xr = Xs + l31 * SC_LD + 4 * half;
     const float* wr = W + ((size_t)c * (K / 8)) * 256 + (size_t)lane * 4;  // fragment-packed (st_pack_weight)
@@ -90,7 +92,7 @@ struct ScorerArgs {
 };
 
 template <bool EDIT>
-__global__ __launch_bounds__(256) void scorer_kernel(ScorerArgs a) {
+__global__ __launch_bounds__(64 * SC_NW) void scorer_kernel(ScorerArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* bufA = smem;
   float* bufB = smem + SC_BUF;
@@ -100,16 +102,16 @@ __global__ __launch_bounds__(256) void scorer_kernel(ScorerArgs a) {
   float* cosv = (float*)(bitsq + 32 * 4);            // [32][32]
   float* coef = cosv + 32 * 32;                      // [32][32]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n;
   const int m0 = blockIdx.x * SC_ROWS;
   if (m0 >= n) return;
   const float* xin = EDIT ? a.latent : a.x;
 
-  // latent tile -> bufA (32 rows x 64 float4 = 2048, 8 per thread)
+  // latent tile -> bufA (32 rows x 64 float4 = 2048)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int f = tid + i * 256;
+  for (int i = 0; i < 2048 / (64 * SC_NW); ++i) {
+    const int f = tid + i * 64 * SC_NW;
     const int r = f >> 6, c4 = f & 63;
     *(f32x4*)(bufA + r * SC_LD + c4 * 4) = *(const f32x4*)(xin + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
   }
@@ -123,8 +125,8 @@ __global__ __launch_bounds__(256) void scorer_kernel(ScorerArgs a) {
 
   if (!EDIT) {
     // z (optionally unit-normalised) -> global; wave handles 8 rows
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr;
+    for (int rr = 0; rr < SC_RPW; ++rr) {
+      const int r = wave * SC_RPW + rr;
       if (m0 + r >= n) continue;
       f32x4 v = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
       if (a.unit) {
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(256) void scorer_kernel(ScorerArgs a) {
     // ---- scores, loss, dL/dp  (p in bufB[.,0:256]; dP -> bufA[.,0:256]) ----
     const int np = a.n_pos, nn = a.n_neg, nt = np + nn;
     const float inv_tau = 1.0f / a.tau;
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr;
+    for (int rr = 0; rr < SC_RPW; ++rr) {
+      const int r = wave * SC_RPW + rr;
       const int b = min(m0 + r, n - 1);
       const f32x4 p = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
       const float pn = fmaxf(sqrtf(wave_sum(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w)), 1e-8f);
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(256) void scorer_kernel(ScorerArgs a) {
     tile_linear<512, 256, false, BWD_NONE>(bufA, bufB, a.w.s1_wt, nullptr, nullptr, 0);
     __syncthreads();
     // ---- Adam (torch.optim.Adam single-tensor path, betas (0.9, 0.999), eps 1e-8) ----
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr;
+    for (int rr = 0; rr < SC_RPW; ++rr) {
+      const int r = wave * SC_RPW + rr;
       const int b = m0 + r;
       if (b >= n) continue;
       const f32x4 g = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
@@ -281,7 +283,7 @@ static int launch_scorer(const ScorerArgs& a, hipStream_t st) {
                                SC_LDS_BYTES));
     attr_done = true;
   }
-  hipLaunchKernelGGL(scorer_kernel<EDIT>, dim3((a.n + SC_ROWS - 1) / SC_ROWS), dim3(256), SC_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(scorer_kernel<EDIT>, dim3((a.n + SC_ROWS - 1) / SC_ROWS), dim3(64 * SC_NW), SC_LDS_BYTES, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
