@@ -28,22 +28,23 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 F16_MFMA_PEAK_TFLOPS = 2516.6
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=20.0, shape="yelp"):
     """The CPU oracle (a numpy port of the reference algorithm, KV-cached decode) on a bounded sample of
     the same workload, on this box's host cores.  Reported beside the GPU number; not the target."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import st_oracle as O
     from style_transfer_amd import weights as W
     from style_transfer_amd.data import AttackSet
-    ae = {k: v.numpy() for k, v in W.expand_ae_state_dict(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors"))).items()}
+    ae = {k: v.numpy() for k, v in W.expand_ae_state_dict(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_%s.safetensors" % shape))).items()}
     ssd = {k: v.numpy() for k, v in W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")).items()}
     psd = {k: v.numpy() for k, v in W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")).items()}
-    data = AttackSet.synthetic(2048, 9339, "yelp", seed=1234)
-    id_to_word = [str(i) for i in range(9339)]
+    V = ae["generator.proj.weight"].shape[0]
+    data = AttackSet.synthetic(2048, V, shape, seed=1234)
+    id_to_word = [str(i) for i in range(V)]
     t0 = time.perf_counter()
     done = 0
     for s in range(len(data)):
-        enc = lambda sents: O.encode_latent(ae, O.pad_sequences(sents, 9339))
+        enc = lambda sents: O.encode_latent(ae, O.pad_sequences(sents, V))
         ori = enc([data.origin[s]])
         like, unlike = enc(data.like[s]), enc(data.unlike[s])
         O.attack_one(ae, ssd, psd, ori, like, unlike, 0.2, id_to_word, lambda m: None, not_nll=True)
@@ -57,8 +58,9 @@ def cpu_baseline(seconds_budget=20.0):
         cores = os.cpu_count()
     cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
     return {"value": done / dt, "unit": "sentences/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic yelp-shaped sentences through oracle/st_oracle.py (numpy f32, batch 1, KV-cached decode with "
-                      "early exit, no log decodes), %.1f s; the imported reference itself ran 12.4 s/sentence on 8 cores (BASELINE.md)" % (done, dt)}
+            "sample": ("%d synthetic %s-shaped sentences through oracle/st_oracle.py (numpy f32, batch 1, KV-cached decode with "
+                       "early exit, no log decodes), %.1f s; the imported reference itself ran 12.4 s/sentence on 8 cores "
+                       "(BASELINE.md, yelp)") % (done, shape, dt)}
 
 
 def main():
@@ -101,7 +103,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors")), dev,
+    # yelp shape: V = 9339; amazon shape: V = 19724 with its own surrogate AE (no amazon weights ship at all)
+    ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)), dev,
                      gemm_format=a.gemm_format)
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
                              W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
@@ -111,11 +114,11 @@ def main():
     B = a.batch
     from style_transfer_amd.data import load_word_counts
     if a.tokens == "real":
-        files = [os.path.join(GOLD, "yelp", "neg10_pos10_test%d.json" % i) for i in (0, 1)]
+        files = [os.path.join(GOLD, a.shape, "neg10_pos10_test%d.json" % i) for i in (0, 1)]
         real = AttackSet.from_json(files, ae.vocab)
         data = real.subset([(i + 137 * rank) % len(real) for i in range(B)])
     else:
-        counts = load_word_counts(os.path.join(GOLD, "yelp", "word_to_id.txt"), ae.vocab) if a.tokens == "zipf" else None
+        counts = load_word_counts(os.path.join(GOLD, a.shape, "word_to_id.txt"), ae.vocab) if a.tokens == "zipf" else None
         data = AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank, word_counts=counts)
     prep = runner.prepare(data)                       # tokens resident in HBM before the timed region
     gidx = torch.arange(B, device=dev) % 1000
@@ -161,7 +164,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d; token ids: %s), %d per GPU per step, flags --attack "
                                    "--not_nll --pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
-                                   "surrogate AE checkpoint + shipped Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes off"
+                                   "surrogate AE checkpoint + shipped (yelp) Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes off"
                                    % (a.shape, {"zipf": "unigram/Zipfian from word_to_id.txt counts", "uniform": "uniform in [4,V)",
                                                 "real": "the real yelp test set tiled"}[a.tokens], B,
                                       "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS"),
@@ -185,7 +188,7 @@ def main():
                          "kernel_time_share": gen_ms.value * 1e-3 / dt},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.shape)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,5 +1,8 @@
 // Stand-alone micro-benchmark of the row-panel GEMM kernels (random data, HIP events).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I style_transfer_amd/csrc tools/kbench.cpp -o build_variants/kbench [-D...]
+// run:   kbench <rows> <generator splits, 0 = auto> <gemm_format 0|1> <kernel letters: g s f q o 2 u t>
+// -D switches (ablations, never in the library build): ST_ABL_NOSTORE (skip output stores), ST_NO_NT (temporal
+// stores), ST_TAIL_STAMPS (cycle stamps of the half-layer kernel's phases, printed after its timing)
 #include "st_rowpanel.h"
 
 #include <stdarg.h>
@@ -162,15 +165,6 @@ int main(int argc, char** argv) {
     printf("  epilogue %llu   total %llu (stamp 0 is after the prologue loads were issued)\n", hs[30] - hs[24], hs[30] - hs[0]);
 #endif
   }
-#ifdef HAVE_LAYER_FUSED
-  {
-    LayerArgs a = {};
-    a.att = att; a.n_host = n; a.wo = wo_p; a.bo = bias; a.x = x; a.ln_a = ln_a; a.ln_b = ln_b; a.w1 = w1_p; a.b1 = bias;
-    a.w2 = w2_p; a.b2 = bias; a.d_ff = DFF;
-    t = timeit([&] { launch_layer_fused(a, n, st); });
-    printf("layer      n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + 2 * DFF) / t / 1e12);
-  }
-#endif
   CK(hipDeviceSynchronize());
   return 0;
 }
