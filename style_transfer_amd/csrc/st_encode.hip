@@ -18,50 +18,8 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
   *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;
 }
 
-// full (non-causal) self-attention inside each sentence; block = sentence, wave = head,
-// lane j = key j (sentence length <= 64), then lane d = output dim.  qkv rows: [q | k | v] (768).
-__global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
-                                                       float* __restrict__ out) {
-  const int s = blockIdx.x;
-  const int r0 = off[s], len = off[s + 1] - r0;
-  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-  if (len <= 16) return;  // short sentences: enc_attn16_kernel
-  // this lane's key row (head slice) stays in registers for all queries
-  f32x4 kreg[16];
-  if (lane < len) {
-    const float* kr = qkv + (size_t)(r0 + lane) * 768 + 256 + h * 64;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) kreg[d] = *(const f32x4*)(kr + d * 4);
-  }
-  for (int i = 0; i < len; ++i) {
-    const float* qr = qkv + (size_t)(r0 + i) * 768 + h * 64;
-    float sc = -INFINITY;
-    if (lane < len) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        const f32x4 qv = *(const f32x4*)(qr + d * 4);
-        acc = fmaf(qv.x, kreg[d].x, acc);
-        acc = fmaf(qv.y, kreg[d].y, acc);
-        acc = fmaf(qv.z, kreg[d].z, acc);
-        acc = fmaf(qv.w, kreg[d].w, acc);
-      }
-      sc = acc * 0.125f;
-    }
-    const float m = wave_max(sc);
-    const float e = lane < len ? expf(sc - m) : 0.0f;
-    const float p = e / wave_sum(e);
-    float o = 0.0f;
-    for (int j = 0; j < len; ++j) o = fmaf(__shfl(p, j, 64), qkv[(size_t)(r0 + j) * 768 + 512 + h * 64 + lane], o);
-    out[(size_t)(r0 + i) * 256 + h * 64 + lane] = o;
-  }
-}
-
-// Sentences of <= 16 tokens (all of yelp): ONE wave per sentence handles the four heads.  Lane l holds dims
-// 4l..4l+3 (head l >> 4) of every K and V row of the sentence in registers (coalesced 1 KiB row loads); for each
-// query the q.k partial sums are reduced over the 16 lanes of a head with DPP row rotations, so the softmax and
-// the PV sum need no further lane traffic (same scheme as attn_step16_kernel in st_decode.hip).
-__device__ __forceinline__ float enc_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in all 16
+// sum over the 16 lanes of a DPP row, result in all 16 (row rotations: no LDS crossbar)
+__device__ __forceinline__ float enc_row16_sum(float v) {
 #define ST_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
   ST_ROW_ADD(0x121);  // row_ror:1
   ST_ROW_ADD(0x122);  // row_ror:2
@@ -71,6 +29,68 @@ __device__ __forceinline__ float enc_row16_sum(float v) {  // sum over the 16 la
   return v;
 }
 
+// Full (non-causal) self-attention inside each sentence of 17..64 tokens (amazon): block = sentence, wave = head.
+// Lane (g = lane >> 4, c = lane & 15) owns the keys j = g, g+4, ... (<= 16 of them) and dims 4c..4c+3 of the
+// head: its K and V slices stay in registers for all queries.  Per query: q.k partial sums are reduced over the
+// 16 lanes of a key group with DPP rotations, the softmax max / sum and the PV partial sums are combined over
+// the four groups with two xor-shuffles each.  qkv rows: [q | k | v] (768 floats).
+__global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
+                                                       float* __restrict__ out) {
+  const int s = blockIdx.x;
+  const int r0 = off[s], len = off[s + 1] - r0;
+  if (len <= 16 || len > 64) return;  // short sentences: enc_attn16_kernel
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const float* base = qkv + (size_t)r0 * 768 + h * 64 + c * 4;
+  const int nk = (len - g + 3) >> 2;  // keys owned by this lane's group: j = g + 4t, t < nk
+  f32x4 kr[16], vr[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < nk) {
+      kr[t] = *(const f32x4*)(base + (size_t)(g + 4 * t) * 768 + 256);
+      vr[t] = *(const f32x4*)(base + (size_t)(g + 4 * t) * 768 + 512);
+    }
+  f32x4 qn = *(const f32x4*)base;
+  for (int i = 0; i < len; ++i) {
+    const f32x4 qv = qn;
+    if (i + 1 < len) qn = *(const f32x4*)(base + (size_t)(i + 1) * 768);
+    float sc[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      sc[t] = -INFINITY;
+      if (t < nk) {
+        const float part = fmaf(qv.x, kr[t].x, fmaf(qv.y, kr[t].y, fmaf(qv.z, kr[t].z, qv.w * kr[t].w)));
+        sc[t] = enc_row16_sum(part) * 0.125f;  // / sqrt(d_k)
+        m = fmaxf(m, sc[t]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
+    f32x4 o4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t < nk) {
+        const float e = expf(sc[t] - m);
+        sum += e;
+        o4 += e * vr[t];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      o4[q] += __shfl_xor(o4[q], 16, 64);
+      o4[q] += __shfl_xor(o4[q], 32, 64);
+    }
+    if (g == 0) *(f32x4*)(out + (size_t)(r0 + i) * 256 + h * 64 + c * 4) = o4 * (1.0f / sum);
+  }
+}
+
+// Sentences of <= 16 tokens (all of yelp): ONE wave per sentence handles the four heads.  Lane l holds dims
+// 4l..4l+3 (head l >> 4) of every K and V row of the sentence in registers (coalesced 1 KiB row loads); for each
+// query the q.k partial sums are reduced over the 16 lanes of a head with DPP row rotations, so the softmax and
+// the PV sum need no further lane traffic (same scheme as attn_step16_kernel in st_decode.hip).
 __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
                                                          int n_sent, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
