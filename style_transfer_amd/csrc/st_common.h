@@ -33,6 +33,20 @@ void st_set_error(const char* fmt, ...);
 
 #define ST_LAUNCH_CHECK() ST_HIP(hipGetLastError())
 
+// Kernels that need more than 64 KiB of dynamic LDS must opt in once PER DEVICE (hipFuncSetAttribute acts on the
+// current device).  `done` is a per-kernel static array indexed by device ordinal.
+#define ST_MAX_DEVICES 64
+#define ST_ENSURE_LDS(fn, bytes)                                                                        \
+  do {                                                                                                  \
+    static bool done_[ST_MAX_DEVICES] = {};                                                             \
+    int dev_ = 0;                                                                                       \
+    ST_HIP(hipGetDevice(&dev_));                                                                        \
+    if (dev_ < 0 || dev_ >= ST_MAX_DEVICES || !done_[dev_]) {                                           \
+      ST_HIP(hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+      if (dev_ >= 0 && dev_ < ST_MAX_DEVICES) done_[dev_] = true;                                       \
+    }                                                                                                   \
+  } while (0)
+
 // Sum over the 64 lanes, result in every lane.  DPP row shifts + row broadcasts (6 VALU ops + one readlane)
 // instead of six ds_bpermute round trips through the LDS crossbar (~100 cycles each): the LayerNorm prologues
 // were spending most of their time there.

@@ -214,12 +214,7 @@ __global__ __launch_bounds__(256) void kloop_gemm_kernel(GemmArgs a) {
 // ---- host-side launch helpers ----
 template <int EPI, bool AT = false, bool WT = false>
 static int launch_kloop(const GemmArgs& a, int n_bound, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)kloop_gemm_kernel<EPI, AT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               ST_KLOOP_LDS));
-    attr_done = true;
-  }
+  ST_ENSURE_LDS((kloop_gemm_kernel<EPI, AT, WT>), ST_KLOOP_LDS);
   if (n_bound <= 0) return ST_OK;
   dim3 grid((n_bound + 127) / 128, (a.N + 127) / 128);
   hipLaunchKernelGGL((kloop_gemm_kernel<EPI, AT, WT>), grid, dim3(256), ST_KLOOP_LDS, st, a);

@@ -365,11 +365,7 @@ static inline int rp_splits(int n_rows, int N, int max_splits, int nw = 4) {
 
 template <int EPI, int NW, bool H>
 static int launch_rp_t(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI, NW, H>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
-    attr_done = true;
-  }
+  ST_ENSURE_LDS((rp_gemm_kernel<EPI, NW, H>), RP_LDS);
   if (n_bound <= 0) return ST_OK;
   dim3 grid((n_bound + 63) / 64, splits);
   hipLaunchKernelGGL((rp_gemm_kernel<EPI, NW, H>), grid, dim3(64 * NW), RP_LDS, st, a);
@@ -377,12 +373,7 @@ static int launch_rp_t(const GemmArgs& a, int n_bound, int splits, hipStream_t s
   return ST_OK;
 }
 static int launch_rp_argmax_screen(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_gemm_kernel<EPI_ARGMAX, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               RP_LDS));
-    attr_done = true;
-  }
+  ST_ENSURE_LDS((rp_gemm_kernel<EPI_ARGMAX, 4, true, true>), RP_LDS);
   if (n_bound <= 0) return ST_OK;
   hipLaunchKernelGGL((rp_gemm_kernel<EPI_ARGMAX, 4, true, true>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
@@ -533,11 +524,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 template <int EPI, bool H>
 static int launch_rp_kchunk_t(const GemmArgs& a, int n_bound, hipStream_t st, int ksplit) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_kchunk_kernel<EPI, H>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
-    attr_done = true;
-  }
+  ST_ENSURE_LDS((rp_kchunk_kernel<EPI, H>), RP_LDS);
   if (n_bound <= 0) return ST_OK;
   if (a.N != 256 || a.K % 256 != 0 || a.K <= 0) {
     st_set_error("rp_kchunk: needs N == 256 and K a multiple of 256 (N=%d K=%d)", a.N, a.K);
@@ -770,11 +757,7 @@ __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
 #define RP_FUSE_MIN_ROWS 65536  /* below this the unfused pair (with column splits) fills the chip better */
 template <bool H>
 static int launch_oproj_ffn1_t(const OFArgs& a, int n_bound, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_oproj_ffn1_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS));
-    attr_done = true;
-  }
+  ST_ENSURE_LDS((rp_oproj_ffn1_kernel<H>), RP_LDS);
   if (n_bound <= 0) return ST_OK;
   hipLaunchKernelGGL(rp_oproj_ffn1_kernel<H>, dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
@@ -989,11 +972,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
 }
 
 static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)rp_layer_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_TAIL_LDS));
-    attr_done = true;
-  }
+  ST_ENSURE_LDS((rp_layer_tail_kernel<0>), RP_TAIL_LDS);
   if (n_bound <= 0) return ST_OK;
   if (a.fmt != ST_GEMM_F16X3 || a.d_ff % 256 != 0 || !a.w2 || !a.b2) {
     st_set_error("rp_layer_tail: needs the f16x3 format, d_ff %% 256 == 0 and w2/b2 (fmt=%d d_ff=%d)", a.fmt, a.d_ff);

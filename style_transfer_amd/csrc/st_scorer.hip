@@ -277,12 +277,7 @@ static int check_scorer(const StScorerWeights* w) {
 
 template <bool EDIT>
 static int launch_scorer(const ScorerArgs& a, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    ST_HIP(hipFuncSetAttribute((const void*)scorer_kernel<EDIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SC_LDS_BYTES));
-    attr_done = true;
-  }
+  ST_ENSURE_LDS((scorer_kernel<EDIT>), SC_LDS_BYTES);
   hipLaunchKernelGGL(scorer_kernel<EDIT>, dim3((a.n + SC_ROWS - 1) / SC_ROWS), dim3(64 * SC_NW), SC_LDS_BYTES, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
