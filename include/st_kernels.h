@@ -8,8 +8,9 @@
  * *_host or is a weights struct (host struct holding device pointers).  Every function returns 0 on
  * success and a negative ST_E* code on failure (st_last_error() gives the text); nothing throws
  * across the boundary; the caller owns every buffer; `stream` is a hipStream_t (0 = default
- * stream).  Kernels are launched asynchronously on `stream`; only st_decode_greedy synchronises it
- * (to read back the live-sentence count, see below).
+ * stream).  Kernels are launched asynchronously on `stream`; st_decode_greedy synchronises it (to
+ * read back the live-sentence count, see below), and in the f16x3 format st_decode_greedy and
+ * st_encode_latent synchronise once more at their end to read the f16-range flag (ST_ERANGE).
  *
  * Arithmetic type everywhere: IEEE f32 (the reference's dtype) in memory and in every non-matrix
  * operation.  Matrix products against packed weights run in one of two operand formats, chosen when
@@ -156,7 +157,9 @@ size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len);
  *   top2gap [B,max_len-1] f32 or NULL: best minus second-best logit at each emitted token (the
  *   record that lets a divergence be traced to an argmax near-tie)
  *   n_steps_host (host int*, may be NULL): number of decode steps actually run.
- * Synchronises `stream` once per `sync_every` steps to read the live count (>=1).               */
+ * Synchronises `stream` once per `sync_every` steps to read the live count (>=1).
+ * With gen_w_maxnorm > 0 in the f16x3 format and top2gap == NULL, steps with >= 2048 live rows use
+ * the screened argmax (one-product pass, then the full product on the undecided rows): same ids.  */
 int st_decode_greedy(const StDecoderWeights* w, const float* latent, int B, int max_len, int bos,
                      int eos, int pad, int options, int sync_every, int32_t* out_ids,
                      float* top2gap, void* workspace, size_t workspace_bytes, int* n_steps_host,
