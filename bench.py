@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-decode", type=int, default=9)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-f32-reference-run", action="store_true",
+                    help="skip the short exact-f32-format run that is reported beside the f16x3 value")
     ap.add_argument("--gemm-format", default="f16x3", choices=["f16x3", "f32"],
                     help="operand format of the AE weight GEMMs: 3-product f16 split (f32-grade results) or exact f32 MFMA")
     a = ap.parse_args()
@@ -147,6 +149,27 @@ def main():
     gen_ms, gen_fl, gen_n = C.c_double(), C.c_double(), C.c_longlong()
     L.st_profile_read(C.byref(gen_ms), C.byref(gen_fl), C.byref(gen_n), 1)
     n_iter_mean = float(r.device["was_active"].sum().item()) / B
+
+    # The same workload once more in the exact-f32 operand format (2 steps after 1 warm-up), reported beside
+    # `value` so that the cost / benefit of the split format can be read from one line.
+    f32_value = None
+    if a.gemm_format == "f16x3" and not a.no_f32_reference_run:
+        del r
+        runner.ws.buf = None
+        torch.cuda.empty_cache()
+        ae32 = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)), dev,
+                           gemm_format="f32")
+        runner32 = AttackRunner(ae32, scorer, cfg, dev)
+        runner32.run_prepared(prep, gidx, fetch=False)
+        sync()
+        t32 = time.perf_counter()
+        for _ in range(2):
+            runner32.run_prepared(prep, gidx, fetch=False)
+        sync()
+        d32 = torch.tensor([time.perf_counter() - t32], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(d32, op=dist.ReduceOp.MAX)
+        f32_value = world * B * 2 / float(d32.item())
     tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -172,6 +195,7 @@ def main():
                        "mean_edit_iterations_per_sentence": n_iter_mean,
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
                        "iters_per_decode": cfg.iters_per_decode, "gemm_format": a.gemm_format,
+                       "same_workload_exact_f32_format_sentences_per_s": f32_value,
                        "edit_iteration_units_per_s": world * units / dt},
             # achieved = ALGORITHMIC flops of the timed kernel / its HIP-event time.  f16x3 issues 3 MFMA flops per
             # algorithmic flop, so frac <= 1/3 there by construction; mfma_issue_frac counts the issued ones.
