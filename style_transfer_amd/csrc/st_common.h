@@ -62,6 +62,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 #undef ST_DPP_ADD
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in all 16: row rotations, no LDS crossbar.
+// The attention kernels put one head on one row (lane = 4 of the head's 64 dims).
+__device__ __forceinline__ float row16_sum(float v) {
+#define ST_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+  ST_ROW_ADD(0x121);  // row_ror:1
+  ST_ROW_ADD(0x122);  // row_ror:2
+  ST_ROW_ADD(0x124);  // row_ror:4
+  ST_ROW_ADD(0x128);  // row_ror:8
+#undef ST_ROW_ADD
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

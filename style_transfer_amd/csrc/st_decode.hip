@@ -144,16 +144,6 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
 // to head l >> 4); q.k partial sums are reduced over the 16 lanes of a head with DPP row shifts, so every lane
 // of a head ends up with all of that head's scores and the softmax needs no further lane traffic; the PV sum
 // is lane-local.  All 2(pos+1) loads of a row are independent and issued up front.
-__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in all 16
-#define ST_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
-  ST_ROW_ADD(0x121);  // row_ror:1
-  ST_ROW_ADD(0x122);  // row_ror:2
-  ST_ROW_ADD(0x124);  // row_ror:4
-  ST_ROW_ADD(0x128);  // row_ror:8
-#undef ST_ROW_ADD
-  return v;
-}
-
 __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
                                                           const float* __restrict__ vbase, long kv_stride,
                                                           const int* __restrict__ idx, const int* __restrict__ n_dev,

@@ -18,17 +18,6 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
   *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;
 }
 
-// sum over the 16 lanes of a DPP row, result in all 16 (row rotations: no LDS crossbar)
-__device__ __forceinline__ float enc_row16_sum(float v) {
-#define ST_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
-  ST_ROW_ADD(0x121);  // row_ror:1
-  ST_ROW_ADD(0x122);  // row_ror:2
-  ST_ROW_ADD(0x124);  // row_ror:4
-  ST_ROW_ADD(0x128);  // row_ror:8
-#undef ST_ROW_ADD
-  return v;
-}
-
 // Full (non-causal) self-attention inside each sentence of 17..64 tokens (amazon): block = sentence, wave = head.
 // Lane (g = lane >> 4, c = lane & 15) owns the keys j = g, g+4, ... (<= 16 of them) and dims 4c..4c+3 of the
 // head: its K and V slices stay in registers for all queries.  Per query: q.k partial sums are reduced over the
@@ -61,7 +50,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
       sc[t] = -INFINITY;
       if (t < nk) {
         const float part = fmaf(qv.x, kr[t].x, fmaf(qv.y, kr[t].y, fmaf(qv.z, kr[t].z, qv.w * kr[t].w)));
-        sc[t] = enc_row16_sum(part) * 0.125f;  // / sqrt(d_k)
+        sc[t] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
         m = fmaxf(m, sc[t]);
       }
     }
@@ -117,7 +106,7 @@ __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict
       sc[j] = -INFINITY;
       if (j < len) {
         const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
-        sc[j] = enc_row16_sum(part) * 0.125f;  // / sqrt(d_k)
+        sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
         m = fmaxf(m, sc[j]);
       }
     }
