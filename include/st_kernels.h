@@ -225,6 +225,22 @@ int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens, const int
                      const int32_t* sent_off, int n_rows, int n_sent, int max_sent_len, float* latent,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (7) Legacy FGIM edit (fgim_attack, model.py:454-516, with Classifier, model.py:414-433; SURVEY §8f
+ * rank 4 — the reference's call sites, main.py:481/:511, are commented out).  For each sentence:
+ *   o = sigmoid(fc3(lrelu(fc2(lrelu(fc1(x))))));  g = d BCELoss(o, target) / d x  (one sentence per loss,
+ *   as in the reference's batch of 1);  out[k][b] = x[b] - eps[k] * g[b]  for the n_eps step sizes
+ * (every epsilon of fgim_attack's list takes exactly one step from the ORIGINAL latent: `it` starts at 4
+ * and the loop ends at it >= 5).  The caller decodes out[] with st_decode_greedy.
+ *   weights: plain row-major nn.Linear tensors (fc1 [100,256], fc2 [50,100], fc3 [1,50]) and biases
+ *   latent [B,256]  target [B] (0/1)  eps [n_eps] (device)  pred [B] or NULL  grad [B,256] or NULL
+ *   out [n_eps,B,256]                                                                              */
+typedef struct StClassifierWeights {
+  const float *w1, *b1, *w2, *b2, *w3, *b3;
+} StClassifierWeights;
+int st_fgim_perturb(const StClassifierWeights* w, const float* latent, const float* target, const float* eps,
+                    int n_eps, int B, float* pred, float* grad, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -388,3 +388,32 @@ def simloss_grads(ori, like, g, tau=0.1, row_offset=0):
     d_ori = (dou - (dou * ou).sum(1, keepdims=True) * ou) / on
     d_like = (dku - (dku * ku).sum(1, keepdims=True) * ku) / kn
     return d_ori, d_like
+
+
+# ------------------------------------------------------------------------------------------------
+# Legacy FGIM path (model.py:414-433 Classifier, :454-516 fgim_attack)
+# ------------------------------------------------------------------------------------------------
+def classifier_forward(csd, x):
+    """Classifier.forward: sigmoid(fc3(lrelu(fc2(lrelu(fc1(x)))))) -> (out [B,1], pre-activations)."""
+    z1 = (x @ csd["fc1.weight"].T + csd["fc1.bias"]).astype(F32)
+    a1 = np.where(z1 > 0, z1, F32(0.2) * z1).astype(F32)
+    z2 = (a1 @ csd["fc2.weight"].T + csd["fc2.bias"]).astype(F32)
+    a2 = np.where(z2 > 0, z2, F32(0.2) * z2).astype(F32)
+    z3 = (a2 @ csd["fc3.weight"].T + csd["fc3.bias"]).astype(F32)
+    return (F32(1) / (F32(1) + np.exp(-z3, dtype=F32))).astype(F32), (z1, z2)
+
+
+def fgim_grad(csd, x, target):
+    """d BCELoss(Classifier(x), target) / d x, one sentence per loss (the reference's batch of 1):
+    dL/dz3 = out - target for sigmoid + BCE."""
+    out, (z1, z2) = classifier_forward(csd, x)
+    dz3 = (out - target.reshape(-1, 1)).astype(F32)
+    d2 = (dz3 @ csd["fc3.weight"]) * np.where(z2 > 0, F32(1), F32(0.2))
+    d1 = (d2 @ csd["fc2.weight"]) * np.where(z1 > 0, F32(1), F32(0.2))
+    return out[:, 0], (d1 @ csd["fc1.weight"]).astype(F32)
+
+
+def fgim_perturb(csd, x, target, epsilons):
+    """fgim_attack: every epsilon takes ONE step from the original latent (it starts at 4, loop ends at it >= 5)."""
+    pred, g = fgim_grad(csd, x, target)
+    return pred, g, np.stack([(x - F32(e) * g).astype(F32) for e in epsilons])

@@ -53,8 +53,13 @@ class StEncoderWeights(C.Structure):
                 ("layer", StEncLayer * ST_MAX_LAYERS)]
 
 
+class StClassifierWeights(C.Structure):
+    _fields_ = [(n, fp) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
+    "st_fgim_perturb": (C.c_int, [C.POINTER(StClassifierWeights), fp, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]),
     "st_abi_version": (C.c_int, []),
     "st_last_error": (C.c_char_p, []),
     "st_profile_enable": (C.c_int, [C.c_int]),

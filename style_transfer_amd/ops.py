@@ -184,3 +184,19 @@ def simloss_bwd(ori, like, lse, g, tau=0.1, row_offset=0, d_like=None):
                                g.data_ptr(), d_ori.data_ptr(), d_like.data_ptr(), scratch.data_ptr(), nb, _stream()),
           "st_simloss_bwd")
     return d_ori, d_like
+
+
+def fgim_perturb(cw, latent, target, eps, want_grad=False):
+    """Classifier forward + BCE backward to the latent + x - eps_k * grad (fgim_attack, model.py:454-516).
+    latent [B,256], target [B] (0/1), eps: sequence of step sizes -> (pred [B], grad [B,256] or None, out [n_eps,B,256])."""
+    _f32(latent)
+    B = latent.shape[0]
+    target = target.to(device=latent.device, dtype=torch.float32).contiguous().view(-1)
+    assert target.numel() == B and latent.shape[1] == 256
+    e = torch.as_tensor(list(eps), dtype=torch.float32, device=latent.device)
+    pred = torch.empty(B, dtype=torch.float32, device=latent.device)
+    grad = torch.empty(B, 256, dtype=torch.float32, device=latent.device) if want_grad else None
+    out = torch.empty(e.numel(), B, 256, dtype=torch.float32, device=latent.device)
+    check(lib().st_fgim_perturb(C.byref(cw.c), latent.data_ptr(), target.data_ptr(), e.data_ptr(), e.numel(), B,
+                                pred.data_ptr(), _p(grad), out.data_ptr(), _stream()), "st_fgim_perturb")
+    return pred, grad, out

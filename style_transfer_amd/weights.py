@@ -161,3 +161,17 @@ class ScorerWeights(_Packed):
             u2p = torch.zeros(256, 128); u2p[:, :hid] = predictor_sd["fc2.weight"]
             c.p1_w, c.p1_wt, c.p1_b = self.packed(u1p), self.packed(u1p.t()), self.dev(c1p)
             c.p2_w, c.p2_wt, c.p2_b = self.packed(u2p), self.packed(u2p.t()), self.dev(predictor_sd["fc2.bias"])
+
+
+class ClassifierWeights(_Packed):
+    """The legacy FGIM style classifier (model.py:414-433: 256 -> 100 -> 50 -> 1) from its state-dict."""
+
+    def __init__(self, sd: dict, device):
+        super().__init__(device)
+        if tuple(sd["fc1.weight"].shape) != (100, 256) or tuple(sd["fc2.weight"].shape) != (50, 100) or \
+                tuple(sd["fc3.weight"].shape) != (1, 50):
+            raise _lib.StError("Classifier shape unsupported: expected fc1 [100,256], fc2 [50,100], fc3 [1,50]")
+        self.c = _lib.StClassifierWeights()
+        for i in (1, 2, 3):
+            setattr(self.c, "w%d" % i, self.dev(sd["fc%d.weight" % i]))
+            setattr(self.c, "b%d" % i, self.dev(sd["fc%d.bias" % i]))

@@ -404,3 +404,45 @@ def test_constraint_loss_wrapper_single_rank(dev):
     assert abs(loss - float(g["loss"])) < 1e-4
     assert relerr(d_ori.cpu().numpy(), g["d_ori"]) < 1e-3
     assert relerr(d_like.cpu().numpy(), g["d_like"]) < 1e-3
+
+
+def test_fgim_matches_reference_and_oracle(dev, ae, ae_sd, id_to_word):
+    """st_fgim_perturb (Classifier forward, BCE backward to the latent, x - eps * grad) and the
+    host driver style_transfer_amd.fgim.fgim_attack against the reference's own run (golden: prediction, gradient,
+    stdout lines, returned text) and, with step sizes large enough to change the decoded text, against the oracle."""
+    from safetensors.torch import load_file
+    from style_transfer_amd import ops
+    from style_transfer_amd.fgim import fgim_attack, EPSILONS
+    from style_transfer_amd.weights import ClassifierWeights
+    from test_oracle_golden import _fgim_reference_lines
+    csd_t = load_file(os.path.join(GOLD, "fgim_classifier.safetensors"))
+    cw = ClassifierWeights(csd_t, dev)
+    g = gold("fgim.npz")
+    lat, tgt = torch.from_numpy(g["latent"]).to(dev), torch.from_numpy(g["target"]).to(dev)
+    pred, grad, out = ops.fgim_perturb(cw, lat, tgt, g["eps"].tolist(), want_grad=True)
+    assert np.abs(pred.cpu().numpy() - g["pred"]).max() < 1e-6
+    assert np.abs(grad.cpu().numpy() - g["grad"]).max() < 1e-5 * np.abs(g["grad"]).max()
+    ref_out = g["latent"][None] - g["eps"][:, None, None] * g["grad"][None]
+    assert np.abs(out.cpu().numpy() - ref_out).max() < 1e-6
+    lines = []
+    texts, _ = fgim_attack(ae, cw, lat, tgt, id_to_word, gold_ids=gold("attack_notnll.npz")["init_ids"][[0, 1, 2, 3, 32, 33, 34, 35]],
+                           log=lines.append)
+    ref = _fgim_reference_lines()
+    per = len(lines) // len(ref)
+    for s, (ref_lines, ret) in enumerate(ref):
+        assert lines[s * per:(s + 1) * per] == ref_lines
+        assert texts[s][-1] == ret
+    # large steps (the reference keeps such a list commented out, model.py:466): texts do change; oracle parity
+    csd = {k: v.numpy() for k, v in csd_t.items()}
+    big = [2.0, 4.0, 8.0, 16.0]
+    _, _, out_big = ops.fgim_perturb(cw, lat, tgt, big)
+    _, _, ref_big = O.fgim_perturb(csd, g["latent"], g["target"], big)
+    assert np.abs(out_big.cpu().numpy() - ref_big).max() < 1e-5
+    ids, _, _ = ops.greedy_decode(ae, out_big.view(-1, 256))
+    ref_ids, ref_gap = O.greedy_decode(ae_sd, ref_big.reshape(-1, 256), early_exit=True, want_gap=True)
+    ids = ids.cpu().numpy()
+    for r in range(ids.shape[0]):
+        if not np.array_equal(ids[r], ref_ids[r]):
+            first = int(np.nonzero(ids[r] != ref_ids[r])[0][0])
+            assert ref_gap[r, first] < 1e-3, (r, first, float(ref_gap[r, first]))
+    assert (ids.reshape(len(big), -1, 59)[-1] != ids.reshape(len(big), -1, 59)[0]).any()   # the texts do change

@@ -86,3 +86,32 @@ def test_simloss_oracle_vs_reference_torch():
         do, dl = O.simloss_grads(g["ori"], g["like"][v], gw, float(g["tau"]))
         assert np.abs(dl - g["d_like"][v]).max() < 1e-3 * np.abs(g["d_like"][v]).max()
     assert abs(tot - float(g["loss"])) < 1e-5
+
+
+def _fgim_reference_lines():
+    """tests/golden/fgim_log.txt: per sentence the reference's stdout and its returned text."""
+    blocks = open(os.path.join(GOLD, "fgim_log.txt")).read().split("=====sentence ")[1:]
+    out = []
+    for b in blocks:
+        body, ret = b.split("=====returned=====\n")
+        out.append((body.split("\n", 1)[1].splitlines(), ret.rstrip("\n")))
+    return out
+
+
+def test_fgim_oracle_vs_reference(ae_sd, id_to_word):
+    """Legacy FGIM path (model.py:414-433, :454-516): prediction, BCE gradient wrt the latent, and the texts the
+    reference prints for its nine step sizes, with a seeded random Classifier (the shipped one is missing)."""
+    from safetensors.numpy import load_file
+    csd = load_file(os.path.join(GOLD, "fgim_classifier.safetensors"))
+    g = gold("fgim.npz")
+    pred, grad, out = O.fgim_perturb(csd, g["latent"], g["target"], g["eps"])
+    assert np.abs(pred - g["pred"]).max() < 1e-6
+    assert np.abs(grad - g["grad"]).max() < 1e-5 * np.abs(g["grad"]).max()
+    ref = _fgim_reference_lines()
+    for s in range(len(ref)):
+        ids = O.greedy_decode(ae_sd, out[:, s], early_exit=True)
+        texts = [O.id2text_sentence(ids[k], id_to_word) for k in range(len(g["eps"]))]
+        lines, ret = ref[s]
+        ref_texts = [lines[i] for i in range(3, len(lines), 3)]        # gold / (epsilon, It, text) x 9
+        assert texts == ref_texts and texts[-1] == ret
+        assert lines[2] == "| It {:2d} | dis model pred {:5.4f} |".format(5, float(pred[s]))
