@@ -68,14 +68,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32768, help="sentences per GPU per step (KV cache: 2.4 MB per sentence)")
+    ap.add_argument("--batch", type=int, default=32768, help="sentences per GPU per step (KV cache: 241 KB per decode job, 12 jobs per sentence in the first round)")
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
     ap.add_argument("--tokens", default="zipf", choices=["zipf", "uniform", "real"],
                     help="synthetic token ids: unigram (Zipfian) from word_to_id.txt counts, uniform in [4,V), or the "
                          "1000 real yelp test sentences tiled to the batch size")
     ap.add_argument("--fixed-steps", action="store_true", help="no early exit at EOS: always 59 decode steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--iters-per-decode", type=int, default=9)
+    ap.add_argument("--iters-per-decode", default="11,7", help="edit iterations decoded per round: an int or a schedule like 9,5,4")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-f32-reference-run", action="store_true",
                     help="skip the short exact-f32-format run that is reported beside the f16x3 value")
@@ -111,7 +111,8 @@ def main():
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
                              W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
     cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, early_exit=not a.fixed_steps,
-                       iters_per_decode=a.iters_per_decode)
+                       iters_per_decode=(int(a.iters_per_decode) if "," not in a.iters_per_decode
+                                         else tuple(int(v) for v in a.iters_per_decode.split(","))))
     runner = AttackRunner(ae, scorer, cfg, dev)
     B = a.batch
     from style_transfer_amd.data import load_word_counts

@@ -50,7 +50,12 @@ class AttackConfig:
     log_decodes: bool = True       # the 1+10+10 decodes behind the Rec:/Sim:/Ref: log lines
     want_gap: bool = False
     want_trace: bool = False       # keep latents / grads / losses per iteration (parity tests)
-    iters_per_decode: int = 9      # edit iterations whose latents are decoded together as one batch
+    # edit iterations whose latents are decoded together as one batch: an int (every round that many) or a
+    # schedule of round sizes, e.g. (9, 3, 3, 3): later rounds are shorter because sentences that reach their 7th
+    # change inside a round have the rest of that round's decodes discarded (44 % of yelp-shaped sentences run all
+    # 18 iterations, the others stop anywhere from iteration 7 on)
+    iters_per_decode: object = (11, 7)
+    defer_stragglers: bool = True  # see run_prepared: sentences whose decodes do not end are finished in an extra round
     count_units: bool = False
 
     @classmethod
@@ -58,6 +63,9 @@ class AttackConfig:
         kw = {k: getattr(ns, k) for k in cls.__dataclass_fields__ if hasattr(ns, k)}
         kw.update(over)
         return cls(**kw)
+
+
+STRAGGLER_LEN = 32   # a decode job with no EOS/PAD among its first 32 tokens marks its sentence as a straggler
 
 
 @dataclass
@@ -177,7 +185,12 @@ class AttackRunner:
         tr = {k: [] for k in ("latent", "grad", "loss", "ids", "gap")} if c.want_trace else None
         max_change = (1 << 30) if c.dance else c.attack_max_change
         dance_rec = []   # --dance: per iteration (loss [B], scores [B, kp + kn])
-        C = 1 if c.retext else max(1, min(c.iters_per_decode, I))   # --retext: the latent itself depends on the decodes
+        if c.retext:
+            sched = [1] * I                   # --retext: the latent itself depends on the decodes
+        elif isinstance(c.iters_per_decode, int):
+            sched = [max(1, min(c.iters_per_decode, I))] * I
+        else:
+            sched = [max(1, int(v)) for v in c.iters_per_decode] + [1] * I
         torch.cuda.synchronize(dev)
         tm["setup_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()
@@ -186,61 +199,96 @@ class AttackRunner:
         # counter and the stop rule, siamese_contrastive.py:812-839), so C edit steps are taken first and
         # their C latents (plus x_0 in the first round) are decoded as ONE batch; the change bookkeeping
         # then replays the iterations in order.  Iterations past a sentence's stop point are discarded.
-        for it0 in range(0, I, C):
-            live = torch.nonzero(active, as_tuple=False).flatten()
-            n_live = int(live.numel())
-            if n_live == 0:
-                break
-            cn = min(C, I - it0)
-            snaps = [ori.index_select(0, live)] if it0 == 0 else []
-            for j in range(cn):
-                out = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, active, tau=c.tau,
-                                           not_nll=c.not_nll, simplest=c.simplest_siamese,
-                                           just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
-                                           want_grad=c.want_trace, want_scores=c.dance)
-                loss, grad = out[0], out[1]
-                if c.dance:
-                    dance_rec.append((loss.cpu().numpy(), out[2].cpu().numpy()))
-                snaps.append(ori.index_select(0, live))
-                if tr is not None:
-                    tr["latent"].append(ori.detach().cpu().numpy().copy())
-                    tr["grad"].append(grad.cpu().numpy())
-                    tr["loss"].append(loss.cpu().numpy())
-            ids, gap, _ = self.decode(torch.cat(snaps, 0), want_gap=want_gap)
-            ids = ids.view(len(snaps), n_live, T)
-            gap = gap.view(len(snaps), n_live, T) if gap is not None else None
-            k0 = 0
-            if it0 == 0:
-                init_ids = torch.zeros(B, T, dtype=torch.int32, device=dev)
-                init_ids.index_copy_(0, live, ids[0])
-                acc_ids = init_ids.clone()
-                if gap is not None:
-                    init_gap = torch.zeros(B, T, device=dev).index_copy_(0, live, gap[0])
-                k0 = 1
-            re_ids = re_lat = None
-            if c.retext:
-                re_lat = self.reencode(ids[k0])
-                re_ids_live, _, _ = self.decode(re_lat)
-                re_ids = torch.zeros(B, T, dtype=torch.int32, device=dev)
-                re_ids.index_copy_(0, live, re_ids_live)
-            for j in range(cn):
-                it = it0 + j
-                was_active[it] = active
-                n_units += int(active.sum().item()) if c.count_units else 0
-                new_ids.index_copy_(0, live, ids[k0 + j])
-                still = active.bool()
-                final_latent[live] = torch.where(still[live, None], snaps[k0 + j], final_latent[live])
-                ops.accept_changes(new_ids, acc_ids, self.ae.vocab, n_changes, changed[it], active, max_change=max_change,
-                                   unk=c.id_unk, eos=c.id_eos, pad=c.id_pad, canon=self.canon, rec_ids=iter_ids[it],
-                                   confirm_ids=re_ids)
+        state = dict(init_ids=None, acc_ids=None, init_gap=None, n_units=0, deferred=None)
+        # Straggler deferral: a handful of decode jobs never emit EOS and keep ~40 almost-empty decode steps alive at the
+        # end of EVERY round.  After the first round the sentences that own such jobs are set aside (sentences are
+        # independent), the other rounds run without those tails, and the set-aside sentences finish their remaining
+        # iterations in one extra round at the end.  Not used where the per-iteration records are taken in lockstep.
+        defer_ok = c.defer_stragglers and not (c.retext or c.dance or c.want_trace) and len([v for v in sched[:I] if v > 1]) > 1
+
+        def rounds(sel, it0, sched):
+            """Run decode rounds for the sentences selected by `sel` (bool [B], None = all) from iteration it0 on."""
+            for C in sched:
+                if it0 >= I:
+                    break
+                mask = active if sel is None else (active & sel.to(torch.uint8))
+                live = torch.nonzero(mask, as_tuple=False).flatten()
+                n_live = int(live.numel())
+                if n_live == 0:
+                    break
+                cn = min(C, I - it0)
+                snaps = [ori.index_select(0, live)] if it0 == 0 else []
+                for j in range(cn):
+                    out = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, mask, tau=c.tau,
+                                               not_nll=c.not_nll, simplest=c.simplest_siamese,
+                                               just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
+                                               want_grad=c.want_trace, want_scores=c.dance)
+                    loss, grad = out[0], out[1]
+                    if c.dance:
+                        dance_rec.append((loss.cpu().numpy(), out[2].cpu().numpy()))
+                    snaps.append(ori.index_select(0, live))
+                    if tr is not None:
+                        tr["latent"].append(ori.detach().cpu().numpy().copy())
+                        tr["grad"].append(grad.cpu().numpy())
+                        tr["loss"].append(loss.cpu().numpy())
+                ids, gap, _ = self.decode(torch.cat(snaps, 0), want_gap=want_gap)
+                ids = ids.view(len(snaps), n_live, T)
+                gap = gap.view(len(snaps), n_live, T) if gap is not None else None
+                k0 = 0
+                if it0 == 0:
+                    state["init_ids"] = torch.zeros(B, T, dtype=torch.int32, device=dev)
+                    state["init_ids"].index_copy_(0, live, ids[0])
+                    state["acc_ids"] = state["init_ids"].clone()
+                    if gap is not None:
+                        state["init_gap"] = torch.zeros(B, T, device=dev).index_copy_(0, live, gap[0])
+                    k0 = 1
+                    if defer_ok:
+                        ended = ((ids == c.id_eos) | (ids == c.id_pad))[:, :, :STRAGGLER_LEN].any(-1)   # [jobs of a sentence, n_live]
+                        strag = (~ended).any(0)
+                        if 0 < int(strag.sum().item()) <= max(64, B // 64):
+                            state["deferred"] = torch.zeros(B, dtype=torch.bool, device=dev)
+                            state["deferred"][live] = strag
+                acc_ids = state["acc_ids"]
+                re_ids = re_lat = None
                 if c.retext:
-                    # accepted: ori_latent.data = re_latent.data (siamese_contrastive.py:826); Adam state carries on
-                    acc_live = changed[it].bool()[live]
-                    ori[live] = torch.where(acc_live[:, None], re_lat, ori[live])
-                    final_latent[live] = torch.where(acc_live[:, None], re_lat, final_latent[live])
-                if tr is not None:
-                    tr["ids"].append(new_ids.cpu().numpy().copy())
-                    tr["gap"].append(torch.zeros(B, T, device=dev).index_copy_(0, live, gap[k0 + j]).cpu().numpy())
+                    re_lat = self.reencode(ids[k0])
+                    re_ids_live, _, _ = self.decode(re_lat)
+                    re_ids = torch.zeros(B, T, dtype=torch.int32, device=dev)
+                    re_ids.index_copy_(0, live, re_ids_live)
+                for j in range(cn):
+                    it = it0 + j
+                    was_active[it] |= mask
+                    state["n_units"] += int(mask.sum().item()) if c.count_units else 0
+                    new_ids.index_copy_(0, live, ids[k0 + j])
+                    still = mask.bool()
+                    final_latent[live] = torch.where(still[live, None], snaps[k0 + j], final_latent[live])
+                    ch = changed[it] if sel is None else torch.zeros(B, dtype=torch.uint8, device=dev)
+                    rec = iter_ids[it] if sel is None else torch.zeros(B, T, dtype=torch.int32, device=dev)
+                    ops.accept_changes(new_ids, acc_ids, self.ae.vocab, n_changes, ch, mask, max_change=max_change,
+                                       unk=c.id_unk, eos=c.id_eos, pad=c.id_pad, canon=self.canon, rec_ids=rec,
+                                       confirm_ids=re_ids)
+                    if sel is not None:   # fold this pass's rows back into the per-iteration records
+                        changed[it] = torch.where(sel, ch, changed[it])
+                        iter_ids[it] = torch.where(sel[:, None], rec, iter_ids[it])
+                        active.copy_(torch.where(sel, mask, active))
+                    if c.retext:
+                        # accepted: ori_latent.data = re_latent.data (siamese_contrastive.py:826); Adam state carries on
+                        acc_live = changed[it].bool()[live]
+                        ori[live] = torch.where(acc_live[:, None], re_lat, ori[live])
+                        final_latent[live] = torch.where(acc_live[:, None], re_lat, final_latent[live])
+                    if tr is not None:
+                        tr["ids"].append(new_ids.cpu().numpy().copy())
+                        tr["gap"].append(torch.zeros(B, T, device=dev).index_copy_(0, live, gap[k0 + j]).cpu().numpy())
+                it0 += cn
+                if it0 == cn and state["deferred"] is not None:
+                    return it0   # first round done and stragglers found: the caller splits the batch
+            return it0
+
+        it_done = rounds(None, 0, sched)
+        if state["deferred"] is not None:
+            rounds(~state["deferred"], it_done, sched[1:])
+            rounds(state["deferred"], it_done, [I])
+        init_ids, acc_ids, init_gap, n_units = state["init_ids"], state["acc_ids"], state["init_gap"], state["n_units"]
         if not c.count_units:
             n_units = int(was_active.sum().item())
         torch.cuda.synchronize(dev)
