@@ -289,6 +289,7 @@ class AttackRunner:
             rounds(~state["deferred"], it_done, sched[1:])
             rounds(state["deferred"], it_done, [I])
         init_ids, acc_ids, init_gap, n_units = state["init_ids"], state["acc_ids"], state["init_gap"], state["n_units"]
+        tm["deferred_sentences"] = 0 if state["deferred"] is None else int(state["deferred"].sum().item())
         if not c.count_units:
             n_units = int(was_active.sum().item())
         torch.cuda.synchronize(dev)
@@ -323,7 +324,7 @@ def concat_results(parts):
     r = AttackResult(cat([p.n_iter for p in parts]), cat([p.init_ids for p in parts]), cat([p.iter_ids for p in parts]),
                      cat([p.changed for p in parts]), cat([p.like_ids for p in parts]), cat([p.unlike_ids for p in parts]),
                      cat([p.final_latent for p in parts]))
-    r.timing = {k: sum(p.timing.get(k, 0) for p in parts) for k in ("setup_s", "loop_s", "units")}
+    r.timing = {k: sum(p.timing.get(k, 0) for p in parts) for k in ("setup_s", "loop_s", "units", "deferred_sentences")}
     if parts and getattr(parts[0], "dance", None):
         r.dance = dict(parts[0].dance, loss=cat([p.dance["loss"] for p in parts]), scores=cat([p.dance["scores"] for p in parts]))
     if parts and parts[0].trace:

@@ -275,6 +275,30 @@ def test_formats_agree_on_8192_synthetic_sentences(scorer_sd_torch, ae_sd_torch)
     assert n_flip <= 0.005 * 8192
 
 
+def test_straggler_deferral_and_round_schedules_do_not_change_results(env):
+    """Sentences are independent, so setting the owners of never-ending decodes aside after the first round, and any
+    schedule of decode rounds, must leave every record bit-identical.  Uniform random tokens make ~0.15 % of the
+    decode jobs run all 59 steps, so the deferral really triggers here (asserted)."""
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet
+    data = AttackSet.synthetic(4096, env["V"], "yelp", seed=5)          # uniform token ids
+    gidx = [i % 1000 for i in range(4096)]
+    base = dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False)
+    runs = {}
+    for name, kw in (("plain", dict(iters_per_decode=9, defer_stragglers=False)),
+                     ("deferred", dict(iters_per_decode=(11, 7), defer_stragglers=True)),
+                     ("fine", dict(iters_per_decode=(6, 5, 4, 3), defer_stragglers=True))):
+        runs[name] = AttackRunner(env["ae"], env["scorer"], AttackConfig(**base, **kw), env["dev"]).run_batch(data, gidx)
+    assert runs["plain"].timing["deferred_sentences"] == 0
+    assert runs["deferred"].timing["deferred_sentences"] > 0, "no straggler in this batch: the test would be vacuous"
+    a = runs["plain"]
+    for name in ("deferred", "fine"):
+        b = runs[name]
+        assert np.array_equal(a.n_iter, b.n_iter) and np.array_equal(a.changed, b.changed)
+        assert np.array_equal(a.iter_ids, b.iter_ids) and np.array_equal(a.init_ids, b.init_ids)
+        assert np.array_equal(a.final_latent, b.final_latent)
+
+
 def test_not_nll_with_unequal_counts_is_rejected_like_the_reference(env):
     """siamese_contrastive.py:429 adds pos_loss [K+] to neg_loss [K-]: a RuntimeError unless K+ == K-."""
     from style_transfer_amd.attack import AttackConfig, AttackRunner
