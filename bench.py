@@ -180,6 +180,19 @@ def main():
         achieved = gen_fl.value / (gen_ms.value * 1e-3) / 1e12 if gen_ms.value > 0 else 0.0
         split = a.gemm_format == "f16x3"
         peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
+        # HBM-side bytes of the roofline kernel come from rocprofv3 counter passes of THIS command (counters cannot be
+        # read from inside the process): profiles/README.md gives the two commands; tools/traffic_from_pmc.py applies
+        # the guide's gfx950 correction.  Only quoted for the configuration the passes were made on.
+        traffic = traffic_src = alg_bytes = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_bench_half_layer_traffic.json")
+        if split and gen_n.value > 0:
+            # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
+            alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
+            default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 32768 and not a.fixed_steps
+                           and a.iters_per_decode == "11,7")
+            if default_cfg and os.path.exists(tfile):
+                traffic = json.load(open(tfile))["bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"
         out = {
             "metric": "style-transferred sentences/sec, yelp-shape" if a.shape == "yelp" else "style-transferred sentences/sec, amazon-shape",
             "value": world * B * a.steps / dt, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -205,7 +218,9 @@ def main():
                                     "2*rows*256*(256+2*d_ff) flop per launch; largest share of GPU time in this format)") if split
                                    else "rp_gemm_kernel<EPI_ARGMAX,4,false> (generator GEMM + fused argmax; 2*rows*256*V flop per launch)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "mfma_flops_per_algorithmic_flop": 3 if split else 1,
                          "mfma_issue_frac": achieved * (3 if split else 1) / peak,
                          "achieved_over_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
