@@ -241,6 +241,57 @@ typedef struct StClassifierWeights {
 int st_fgim_perturb(const StClassifierWeights* w, const float* latent, const float* target, const float* eps,
                     int n_eps, int B, float* pred, float* grad, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (8) One optimisation step of the style scorer: the loop body of train_contrastive
+ * (siamese_contrastive.py:918-931) — SiameseNet (:29-62) and Predictor (:66-86) in TRAIN mode
+ * (BatchNorm batch statistics per call, Dropout 0.2), get_contrastive_loss in its NLL form (:367-453), gradients of
+ * every parameter, BatchNorm running statistics, and torch.optim.Adam (:881-883, :929-931) as a second call so a
+ * data-parallel caller can all-reduce `grads` in between.
+ *
+ *   params / grads / adam_m / adam_v   flat f32 [ST_TP_COUNT], tensors in the order of
+ *        list(siamese_net.parameters()) + list(predictor_net.parameters()), nn.Linear weights row-major [out,in]
+ *   bn   flat f32 [ST_TB_COUNT]: running_mean / running_var of SiameseNet.norm1, .norm2, Predictor.norm1 (in/out)
+ *   x    [1+Kp+Kn, B, 256] latents of the calls in the reference's order: ori, like_0.., unlike_0.. (:380-382)
+ *   keep_masks  u8 [1+Kp+Kn][2][B][512] (1 = keep) for SiameseNet.d1 / .d2 of every call, or NULL: the keep decision
+ *        is then a counter hash of (seed, element) — pass a fresh seed every step
+ *   flags  ST_F_SIMPLEST (--simplest_siamese: no Predictor, like / unlike outputs NOT detached, :384-400),
+ *          ST_F_JUST_USE_ONE (:449-452)
+ *   loss_out [1] (device)   choice_out [Kp,B] i32 or NULL: argmax of each log-softmax row (0 = the positive won; the
+ *        reference's accuracy counter, :926-933)
+ * Requires B >= 2, 1 <= Kp, 1 <= Kn, Kp + Kn <= 64.  In ST_F_SIMPLEST mode the Predictor entries of grads are 0.     */
+#define ST_TP_S_FC1_W 0
+#define ST_TP_S_FC1_B 131072
+#define ST_TP_S_BN1_G 131584
+#define ST_TP_S_BN1_B 132096
+#define ST_TP_S_FC2_W 132608
+#define ST_TP_S_FC2_B 394752
+#define ST_TP_S_BN2_G 395264
+#define ST_TP_S_BN2_B 395776
+#define ST_TP_S_FC3_W 396288
+#define ST_TP_S_FC3_B 527360
+#define ST_TP_SIAMESE_COUNT 527616   /* the optimizer of --simplest_siamese covers only these (:877-879) */
+#define ST_TP_P_FC1_W 527616
+#define ST_TP_P_FC1_B 553216
+#define ST_TP_P_BN_G 553316
+#define ST_TP_P_BN_B 553416
+#define ST_TP_P_FC2_W 553516
+#define ST_TP_P_FC2_B 579116
+#define ST_TP_COUNT 579372
+#define ST_TB_S_RM1 0
+#define ST_TB_S_RV1 512
+#define ST_TB_S_RM2 1024
+#define ST_TB_S_RV2 1536
+#define ST_TB_P_RM 2048
+#define ST_TB_P_RV 2148
+#define ST_TB_COUNT 2248
+int st_scorer_train_workspace_bytes(int B, int Kp, int Kn, int flags, size_t* bytes);
+int st_scorer_train_step(const float* params, float* bn, const float* x, int B, int Kp, int Kn, float tau, int flags,
+                         float drop_p, const uint8_t* keep_masks, uint64_t seed, float* grads, float* loss_out,
+                         int32_t* choice_out, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.Adam with default options (no weight decay, no amsgrad) over n elements; step is 1-based.  */
+int st_adam_step(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

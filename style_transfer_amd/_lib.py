@@ -79,6 +79,10 @@ EXPORTS = {
     "st_simloss_fwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, C.c_size_t, fp]),
     "st_simloss_bwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, fp, fp, C.c_size_t, fp]),
     "st_encode_workspace_bytes": (C.c_size_t, [C.POINTER(StEncoderWeights), C.c_int, C.c_int]),
+    "st_scorer_train_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "st_scorer_train_step": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, fp, C.c_uint64,
+                                       fp, fp, fp, fp, C.c_size_t, fp]),
+    "st_adam_step": (C.c_int, [fp, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp]),
     "st_encode_latent": (C.c_int, [C.POINTER(StEncoderWeights), fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
 }
 

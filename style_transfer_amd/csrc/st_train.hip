@@ -1,0 +1,547 @@
+// One optimisation step of the style scorer (first half): the body of the reference's
+// train_contrastive loop (siamese_contrastive.py:918-931) for SiameseNet (:29-62) + Predictor (:66-86) in TRAIN mode.
+//
+//   forward   G = 1 + Kp + Kn SiameseNet calls of B rows each (ori, like_0.., unlike_0..: :380-382), every call with
+//             its OWN BatchNorm batch statistics and Dropout(0.2) masks; Predictor on the ori call (:405);
+//             cosine scores / tau (:409-417); NLL of log_softmax([pos_i, neg_0..]) per positive (:438-453)
+//   backward  to every parameter.  like / unlike outputs are detached in Predictor mode (:406-407), so only the B rows
+//             of the ori call carry gradient; with --simplest_siamese (:384-400) nothing is detached and all G calls do
+//   running statistics of the three BatchNorm layers: G (resp. 1) momentum-0.1 updates in call order
+//   st_adam_step: torch.optim.Adam (defaults) over the flat parameter vector
+//
+// Layout: all trainable parameters live in ONE flat f32 vector in the order of
+// list(siamese_net.parameters()) + list(predictor_net.parameters()) (:881-882; offsets ST_TP_* in st_kernels.h), so the
+// optimizer is one elementwise kernel and a data-parallel job all-reduces the gradient as one RCCL bucket.
+// The matrix products are f32 MFMA (v_mfma_f32_32x32x2_f32) on 64x64 LDS tiles with arbitrary operand strides (one
+// kernel serves Y = X.W^T, dX = dY.W and dW = dY^T.X); dW contracts over rows in slabs that a second kernel sums in a
+// fixed order, so a step is bit-reproducible.  At the reference's batch (128) the step is launch-bound (~50 launches).
+#include <math.h>
+
+#include "st_common.h"
+
+#define TR_EPS 1e-5f
+#define TR_MOM 0.1f
+
+// ------------------------------------------------------------------------------------------------
+// C[i,j] (+bias[j]) = sum_r A(i,r) * B(r,j),   A(i,r) = A[i*sai + r*sar],  B(r,j) = B[r*sbr + j*sbj]
+// blockIdx.z = slab of the contraction range [z*rper, (z+1)*rper) -> C + z*slab
+// ------------------------------------------------------------------------------------------------
+struct TgArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, R;
+  long sai, sar, sbr, sbj;
+  int ldc, rper;
+  long slab;
+};
+#define TG_LD 68
+__global__ __launch_bounds__(256) void tg_gemm_kernel(TgArgs a) {
+  __shared__ float As[16][TG_LD], Bs[16][TG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int r0 = blockIdx.z * a.rper, r1 = min(a.R, r0 + a.rper);
+  const bool a_r_fast = a.sar == 1, b_r_fast = a.sbr == 1;
+  float ra[4], rb[4];
+  auto fetch = [&](int rc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int ar = a_r_fast ? (e & 15) : (e >> 6), ai = a_r_fast ? (e >> 4) : (e & 63);
+      const int br = b_r_fast ? (e & 15) : (e >> 6), bj = b_r_fast ? (e >> 4) : (e & 63);
+      ra[q] = (i0 + ai < a.M && rc + ar < r1) ? a.A[(long)(i0 + ai) * a.sai + (long)(rc + ar) * a.sar] : 0.0f;
+      rb[q] = (j0 + bj < a.N && rc + br < r1) ? a.B[(long)(rc + br) * a.sbr + (long)(j0 + bj) * a.sbj] : 0.0f;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32, l31 = lane & 31, half = lane >> 5;
+  if (r0 < r1) fetch(r0);
+  for (int rc = r0; rc < r1; rc += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int ar = a_r_fast ? (e & 15) : (e >> 6), ai = a_r_fast ? (e >> 4) : (e & 63);
+      const int br = b_r_fast ? (e & 15) : (e >> 6), bj = b_r_fast ? (e >> 4) : (e & 63);
+      As[ar][ai] = ra[q];
+      Bs[br][bj] = rb[q];
+    }
+    __syncthreads();
+    if (rc + 16 < r1) fetch(rc + 16);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) acc = mfma32(As[2 * kk + half][wi + l31], Bs[2 * kk + half][wj + l31], acc);
+  }
+  float* C = a.C + (long)blockIdx.z * a.slab;
+  const int j = j0 + wj + l31;
+  const float bj = (a.bias && j < a.N) ? a.bias[j] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wi + mfma32_row(r, lane);
+    if (i < a.M && j < a.N) C[(long)i * a.ldc + j] = acc[r] + bj;
+  }
+}
+
+// out[e] = sum_s in[s*stride + e]   (fixed order: reproducible)
+__global__ __launch_bounds__(256) void tr_slab_sum_kernel(const float* __restrict__ in, int nslab, long stride, long n,
+                                                          float* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.0f;
+  for (int k = 0; k < nslab; ++k) s += in[k * stride + e];
+  out[e] = s;
+}
+
+// column sums of X[rows, N] over row slabs: part[z][col] = sum_{row in slab z} X[row][col]
+__global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict__ X, int rows, int N, int rper,
+                                                        float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
+  float s = 0.0f;
+  if (c < N)
+    for (int r = r0 + rg; r < r1; r += 4) s += X[(long)r * N + c];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < N) part[(long)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- BatchNorm (train mode), one statistic set per (call g, feature) ----
+// grid (ceil(N/64), G): mean and BIASED variance of H[g*B .. g*B+B, col], two passes
+__global__ __launch_bounds__(256) void tr_bn_stats_kernel(const float* __restrict__ H, int B, int N, float* __restrict__ mean,
+                                                          float* __restrict__ var) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rg = threadIdx.x >> 6, g = blockIdx.y;
+  const float* Hg = H + (long)g * B * N;
+  float s = 0.0f;
+  if (c < N)
+    for (int r = rg; r < B; r += 4) s += Hg[(long)r * N + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  const float mu = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)B;
+  __syncthreads();
+  float q = 0.0f;
+  if (c < N)
+    for (int r = rg; r < B; r += 4) {
+      const float d = Hg[(long)r * N + c] - mu;
+      q = fmaf(d, d, q);
+    }
+  red[rg][cl] = q;
+  __syncthreads();
+  if (rg == 0 && c < N) {
+    mean[(long)g * N + c] = mu;
+    var[(long)g * N + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)B;
+  }
+}
+// running statistics: G sequential momentum updates in call order (unbiased variance, as nn.BatchNorm1d)
+__global__ __launch_bounds__(256) void tr_bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var, int G,
+                                                            int N, int B, float* __restrict__ rm, float* __restrict__ rv) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float m = rm[c], v = rv[c];
+  const float ub = (float)B / (float)(B - 1);
+  for (int g = 0; g < G; ++g) {
+    m = (1.0f - TR_MOM) * m + TR_MOM * mean[(long)g * N + c];
+    v = (1.0f - TR_MOM) * v + TR_MOM * (var[(long)g * N + c] * ub);
+  }
+  rm[c] = m;
+  rv[c] = v;
+}
+
+// Dropout keep decision: explicit mask (parity tests replay the reference's masks) or a counter hash of
+// (seed, element index) — stateless, so the backward pass regenerates the forward's decision.
+__device__ __forceinline__ bool tr_keep(const uint8_t* mask, unsigned long long seed, long idx, float drop_p) {
+  if (mask) return mask[idx] != 0;
+  unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1);
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (float)(x >> 40) * (1.0f / 16777216.0f) >= drop_p;
+}
+
+// A = dropout(act(gamma * (H - mean) / sqrt(var + eps) + beta)); slope 0 = ReLU, 0.2 = LeakyReLU; one thread per element
+// keep-mask layout [G calls][2 layers][B][N]
+struct BnActArgs {
+  const float* H;
+  const float* mean;
+  const float* var;
+  const float* gamma;
+  const float* beta;
+  float* A;
+  const uint8_t* mask;
+  unsigned long long seed;
+  int B, N, layer, rows;
+  float slope, drop_p;
+  // backward only
+  const float* dA;
+  const float* sums;  // [G][2][N]: sum dy, sum dy*xhat
+  float* dH;
+};
+__device__ __forceinline__ long tr_mask_index(int g, int layer, int b, int c, int B, int N) {
+  return (((long)g * 2 + layer) * B + b) * N + c;
+}
+__global__ __launch_bounds__(256) void tr_bn_act_kernel(BnActArgs a) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)a.rows * a.N) return;
+  const int row = (int)(e / a.N), c = (int)(e - (long)row * a.N), g = row / a.B, b = row - g * a.B;
+  const float inv = 1.0f / sqrtf(a.var[(long)g * a.N + c] + TR_EPS);
+  const float y = (a.H[e] - a.mean[(long)g * a.N + c]) * inv * a.gamma[c] + a.beta[c];
+  float v = y > 0.0f ? y : a.slope * y;
+  if (a.drop_p > 0.0f) v = tr_keep(a.mask, a.seed, tr_mask_index(g, a.layer, b, c, a.B, a.N), a.drop_p) ? v * (1.0f / (1.0f - a.drop_p)) : 0.0f;
+  a.A[e] = v;
+}
+// dy = dA * dropout' * act'(y);  the two column sums BatchNorm's backward needs: sums[g][0][c] = sum dy (= d beta),
+// sums[g][1][c] = sum dy * xhat (= d gamma).  grid (ceil(N/64), G)
+__device__ __forceinline__ float tr_dy(const BnActArgs& a, long e, int g, int b, int c, float& xhat) {
+  const float inv = 1.0f / sqrtf(a.var[(long)g * a.N + c] + TR_EPS);
+  xhat = (a.H[e] - a.mean[(long)g * a.N + c]) * inv;
+  const float y = xhat * a.gamma[c] + a.beta[c];
+  float d = a.dA[e];
+  if (a.drop_p > 0.0f) d = tr_keep(a.mask, a.seed, tr_mask_index(g, a.layer, b, c, a.B, a.N), a.drop_p) ? d * (1.0f / (1.0f - a.drop_p)) : 0.0f;
+  return y > 0.0f ? d : a.slope * d;
+}
+__global__ __launch_bounds__(256) void tr_bn_bwd_sums_kernel(BnActArgs a) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rg = threadIdx.x >> 6, g = blockIdx.y;
+  float s1 = 0.0f, s2 = 0.0f;
+  if (c < a.N)
+    for (int b = rg; b < a.B; b += 4) {
+      float xh;
+      const float dy = tr_dy(a, ((long)g * a.B + b) * a.N + c, g, b, c, xh);
+      s1 += dy;
+      s2 = fmaf(dy, xh, s2);
+    }
+  red[0][rg][cl] = s1;
+  red[1][rg][cl] = s2;
+  __syncthreads();
+  if (rg == 0 && c < a.N) {
+    float* o = (float*)a.sums + (long)g * 2 * a.N;
+    o[c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    o[a.N + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  }
+}
+// dH = gamma * inv / B * (B*dy - sum dy - xhat * sum dy*xhat)
+__global__ __launch_bounds__(256) void tr_bn_bwd_apply_kernel(BnActArgs a) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)a.rows * a.N) return;
+  const int row = (int)(e / a.N), c = (int)(e - (long)row * a.N), g = row / a.B, b = row - g * a.B;
+  float xh;
+  const float dy = tr_dy(a, e, g, b, c, xh);
+  const float inv = 1.0f / sqrtf(a.var[(long)g * a.N + c] + TR_EPS);
+  const float* s = a.sums + (long)g * 2 * a.N;
+  a.dH[e] = a.gamma[c] * inv / (float)a.B * ((float)a.B * dy - s[c] - xh * s[a.N + c]);
+}
+
+// ---- scores, loss, d(loss)/d(scores) ----
+// one wave per batch row b: cosine of p[b] with the K = Kp+Kn reference outputs Z[1+k][b]; per-positive NLL term and
+// the reference's `choice` (argmax of the log-softmax row, first maximum wins)
+__global__ __launch_bounds__(256) void tr_score_kernel(const float* __restrict__ P, const float* __restrict__ Z, int B, int Kp, int Kn,
+                                                       float tau, float* __restrict__ S, float* __restrict__ lossrow,
+                                                       int32_t* __restrict__ choice) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int K = Kp + Kn;
+  const f32x4 p = *(const f32x4*)(P + (long)b * 256 + lane * 4);
+  const float pn = fmaxf(sqrtf(wave_sum(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w)), 1e-8f);
+  float mine = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const f32x4 z = *(const f32x4*)(Z + ((long)(1 + k) * B + b) * 256 + lane * 4);
+    const float zn = fmaxf(sqrtf(wave_sum(z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w)), 1e-8f);
+    const float s = wave_sum(p.x * z.x + p.y * z.y + p.z * z.z + p.w * z.w) / (pn * zn) / tau;
+    if (lane == k) mine = s;
+  }
+  if (lane < K) S[(long)b * K + lane] = mine;
+  // negatives: lanes Kp..K-1
+  const bool isneg = lane >= Kp && lane < K;
+  const float nmax = wave_max(isneg ? mine : -INFINITY);
+  const float nsum = wave_sum(isneg ? expf(mine - nmax) : 0.0f);
+  // first negative lane holding the maximum
+  const unsigned long long eq = __ballot(isneg && mine == nmax);
+  const int nfirst = eq ? __builtin_ctzll(eq) - Kp : 0;
+  for (int i = 0; i < Kp; ++i) {
+    const float si = __shfl(mine, i, 64);
+    const float m = Kn > 0 ? fmaxf(si, nmax) : si;
+    const float sum = expf(si - m) + (Kn > 0 ? nsum * expf(nmax - m) : 0.0f);
+    if (lane == 0) {
+      lossrow[(long)i * B + b] = -(si - m - logf(sum));
+      choice[(long)i * B + b] = (Kn > 0 && nmax > si) ? 1 + nfirst : 0;
+    }
+  }
+}
+// one block: L_i = mean_b lossrow[i][b]; loss = mean_i L_i, or min_i (first minimum) with just_use_one (:448-452)
+__global__ __launch_bounds__(256) void tr_loss_kernel(const float* __restrict__ lossrow, int B, int Kp, int just_one,
+                                                      float* __restrict__ loss_out, int32_t* __restrict__ sel) {
+  __shared__ float red[256];
+  __shared__ float Ls[64];
+  for (int i = 0; i < Kp; ++i) {
+    float s = 0.0f;
+    for (int b = threadIdx.x; b < B; b += 256) s += lossrow[(long)i * B + b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) Ls[i] = red[0] / (float)B;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (just_one) {
+      int k = 0;
+      for (int i = 1; i < Kp; ++i)
+        if (Ls[i] < Ls[k]) k = i;
+      *loss_out = Ls[k];
+      *sel = k;
+    } else {
+      float s = 0.0f;
+      for (int i = 0; i < Kp; ++i) s += Ls[i];
+      *loss_out = s / (float)Kp;
+      *sel = -1;
+    }
+  }
+}
+// one wave per row b: d loss / d scores from the softmax rows, then through cos = pu . zu:
+//   dP[b] = (sum_k dcos_k zu_k - (sum_k dcos_k cos_k) pu) / |p|;   simplest mode also dZ[1+k][b] = dcos_k (pu - cos_k zu_k) / |z_k|
+// (dOut rows: group 0 = dP; in simplest mode groups 1..K = dZ)
+__global__ __launch_bounds__(256) void tr_dscore_kernel(const float* __restrict__ P, const float* __restrict__ Z, const float* __restrict__ S,
+                                                        const int32_t* __restrict__ sel, int B, int Kp, int Kn, float tau,
+                                                        int want_dz, float* __restrict__ dOut) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int K = Kp + Kn, only = *sel;
+  const float mine = lane < K ? S[(long)b * K + lane] : -INFINITY;
+  const bool isneg = lane >= Kp && lane < K;
+  const float nmax = wave_max(isneg ? mine : -INFINITY);
+  const float nsum = wave_sum(isneg ? expf(mine - nmax) : 0.0f);
+  float ds = 0.0f;
+  const float wgt = (only >= 0 ? 1.0f : 1.0f / (float)Kp) / (float)B;
+  for (int i = 0; i < Kp; ++i) {
+    if (only >= 0 && i != only) continue;
+    const float si = __shfl(mine, i, 64);
+    const float m = Kn > 0 ? fmaxf(si, nmax) : si;
+    const float lse = m + logf(expf(si - m) + (Kn > 0 ? nsum * expf(nmax - m) : 0.0f));
+    if (lane == i) ds += wgt * (expf(si - lse) - 1.0f);
+    if (isneg) ds += wgt * expf(mine - lse);
+  }
+  const float dcos = ds / tau;
+  const f32x4 p = *(const f32x4*)(P + (long)b * 256 + lane * 4);
+  const float pn = fmaxf(sqrtf(wave_sum(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w)), 1e-8f);
+  const f32x4 pu = p / pn;
+  f32x4 acc = {0, 0, 0, 0};
+  float csum = 0.0f;
+  for (int k = 0; k < K; ++k) {
+    const f32x4 z = *(const f32x4*)(Z + ((long)(1 + k) * B + b) * 256 + lane * 4);
+    const float zn = fmaxf(sqrtf(wave_sum(z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w)), 1e-8f);
+    const f32x4 zu = z / zn;
+    const float cs = wave_sum(pu.x * zu.x + pu.y * zu.y + pu.z * zu.z + pu.w * zu.w);
+    const float dk = __shfl(dcos, k, 64);
+    acc += dk * zu;
+    csum = fmaf(dk, cs, csum);
+    if (want_dz) *(f32x4*)(dOut + ((long)(1 + k) * B + b) * 256 + lane * 4) = dk * (pu - cs * zu) / zn;
+  }
+  *(f32x4*)(dOut + (long)b * 256 + lane * 4) = (acc - csum * pu) / pn;
+}
+
+// torch.optim.Adam, defaults (no weight decay, no amsgrad)
+__global__ __launch_bounds__(256) void tr_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, long n, float b1, float b2, float eps,
+                                                      float lr_over_bc1, float inv_sqrt_bc2) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float ge = g[e];
+  const float me = m[e] + (1.0f - b1) * (ge - m[e]);
+  const float ve = v[e] * b2 + (1.0f - b2) * ge * ge;
+  m[e] = me;
+  v[e] = ve;
+  p[e] -= lr_over_bc1 * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct TrainWs {
+  float *H1, *A1, *H2, *A2, *Z, *mean1, *var1, *mean2, *var2;
+  float *HP, *Q, *P, *pmean, *pvar, *S, *lossrow, *dP, *dZ, *d512a, *d512b, *dQ, *sums, *slabs, *colpart;
+  int32_t *choice, *sel;
+  size_t bytes;
+};
+inline size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
+constexpr int TR_MAX_SLABS = 16;
+TrainWs train_layout(char* base, int B, int Kp, int Kn, bool simplest) {
+  const size_t G = 1 + Kp + Kn, Gb = simplest ? G : 1, GB = G * B, GbB = Gb * B;
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = (float*)(base + off);
+    off += up64(nfloat) * 4;
+    return p;
+  };
+  TrainWs w;
+  w.H1 = take(GB * 512); w.A1 = take(GB * 512); w.H2 = take(GB * 512); w.A2 = take(GB * 512); w.Z = take(GB * 256);
+  w.mean1 = take(G * 512); w.var1 = take(G * 512); w.mean2 = take(G * 512); w.var2 = take(G * 512);
+  w.HP = take((size_t)B * 100); w.Q = take((size_t)B * 100); w.P = take((size_t)B * 256); w.pmean = take(128); w.pvar = take(128);
+  w.S = take((size_t)B * 64); w.lossrow = take((size_t)B * 64);
+  w.dP = take((size_t)B * 256); w.dZ = take(GbB * 256); w.d512a = take(GbB * 512); w.d512b = take(GbB * 512); w.dQ = take((size_t)B * 100);
+  w.sums = take(Gb * 2 * 512); w.slabs = take((size_t)TR_MAX_SLABS * 512 * 512); w.colpart = take((size_t)TR_MAX_SLABS * 512);
+  w.choice = (int32_t*)take((size_t)B * 64); w.sel = (int32_t*)take(64);
+  w.bytes = off;
+  return w;
+}
+int tr_slabs(int R) {
+  int s = R / 256;
+  return s < 1 ? 1 : (s > TR_MAX_SLABS ? TR_MAX_SLABS : s);
+}
+int gemm(hipStream_t st, const float* A, long sai, long sar, const float* Bm, long sbr, long sbj, float* C, int ldc, const float* bias,
+         int M, int N, int R, int nslab = 1, long slab = 0) {
+  TgArgs a{A, Bm, C, bias, M, N, R, sai, sar, sbr, sbj, ldc, 0, slab};
+  a.rper = ((R + nslab - 1) / nslab + 15) / 16 * 16;
+  hipLaunchKernelGGL(tg_gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, nslab), dim3(256), 0, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+// dW[N,K] = dY[rows,N]^T . X[rows,K]  and  db[N] = column sums of dY, both reduced over row slabs in a fixed order
+int weight_grads(hipStream_t st, const TrainWs& w, const float* dY, const float* X, int rows, int N, int K, float* dW, float* db) {
+  const int ns = tr_slabs(rows);
+  int rc = gemm(st, dY, 1, N, X, K, 1, ns == 1 ? dW : w.slabs, K, nullptr, N, K, rows, ns, (long)N * K);
+  if (rc != ST_OK) return rc;
+  if (ns > 1) {
+    hipLaunchKernelGGL(tr_slab_sum_kernel, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, st, w.slabs, ns, (long)N * K, (long)N * K, dW);
+    ST_LAUNCH_CHECK();
+  }
+  const int rper = (rows + ns - 1) / ns;
+  hipLaunchKernelGGL(tr_colsum_kernel, dim3((N + 63) / 64, ns), dim3(256), 0, st, dY, rows, N, rper, ns == 1 ? db : w.colpart);
+  ST_LAUNCH_CHECK();
+  if (ns > 1) {
+    hipLaunchKernelGGL(tr_slab_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, st, w.colpart, ns, (long)N, (long)N, db);
+    ST_LAUNCH_CHECK();
+  }
+  return ST_OK;
+}
+}  // namespace
+
+extern "C" int st_scorer_train_workspace_bytes(int B, int Kp, int Kn, int flags, size_t* bytes) {
+  ST_CHECK_ARG(bytes && B >= 2 && Kp >= 1 && Kn >= 1 && Kp + Kn <= 64, "B=%d Kp=%d Kn=%d (B >= 2, Kp >= 1, Kn >= 1, Kp+Kn <= 64)", B, Kp, Kn);
+  *bytes = train_layout(nullptr, B, Kp, Kn, (flags & ST_F_SIMPLEST) != 0).bytes;
+  return ST_OK;
+}
+
+extern "C" int st_scorer_train_step(const float* params, float* bn, const float* x, int B, int Kp, int Kn, float tau, int flags,
+                                    float drop_p, const uint8_t* keep_masks, uint64_t seed, float* grads, float* loss_out,
+                                    int32_t* choice_out, void* workspace, size_t workspace_bytes, void* stream) {
+  ST_CHECK_ARG(params && bn && x && grads && loss_out && workspace, "NULL buffer");
+  ST_CHECK_ARG(B >= 2 && Kp >= 1 && Kn >= 1 && Kp + Kn <= 64, "B=%d Kp=%d Kn=%d (B >= 2: BatchNorm needs a batch; Kp, Kn >= 1: the NLL form needs both; Kp+Kn <= 64)", B, Kp, Kn);
+  ST_CHECK_ARG(tau > 0.0f && drop_p >= 0.0f && drop_p < 1.0f, "tau=%g drop_p=%g", tau, drop_p);
+  ST_CHECK_ARG((flags & ~(ST_F_SIMPLEST | ST_F_JUST_USE_ONE)) == 0, "flags=%d: only ST_F_SIMPLEST / ST_F_JUST_USE_ONE apply to training", flags);
+  const bool simplest = (flags & ST_F_SIMPLEST) != 0;
+  hipStream_t st = (hipStream_t)stream;
+  const TrainWs w = train_layout((char*)workspace, B, Kp, Kn, simplest);
+  if (w.bytes > workspace_bytes) {
+    st_set_error("st_scorer_train_step: workspace %zu bytes < %zu needed", workspace_bytes, w.bytes);
+    return ST_ENOMEM;
+  }
+  const int G = 1 + Kp + Kn, Gb = simplest ? G : 1, GB = G * B, GbB = Gb * B, K = Kp + Kn;
+  const float* pr = params;
+  float* gr = grads;
+  int rc;
+#define TR_RUN(call)        \
+  do {                      \
+    rc = (call);            \
+    if (rc != ST_OK) return rc; \
+  } while (0)
+  auto blocks = [](long n) { return dim3((unsigned)((n + 255) / 256)); };
+  auto bnargs = [&](const float* H, const float* mean, const float* var, int gofs, int bofs, float* A, int layer, int N, int rows, float slope, float dp) {
+    BnActArgs a{};
+    a.H = H; a.mean = mean; a.var = var; a.gamma = pr + gofs; a.beta = pr + bofs; a.A = A; a.mask = keep_masks; a.seed = seed;
+    a.B = B; a.N = N; a.layer = layer; a.rows = rows; a.slope = slope; a.drop_p = dp;
+    return a;
+  };
+  // ---------------- forward ----------------
+  TR_RUN(gemm(st, x, 256, 1, pr + ST_TP_S_FC1_W, 1, 256, w.H1, 512, pr + ST_TP_S_FC1_B, GB, 512, 256));
+  hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(8, G), dim3(256), 0, st, w.H1, B, 512, w.mean1, w.var1);
+  BnActArgs f1 = bnargs(w.H1, w.mean1, w.var1, ST_TP_S_BN1_G, ST_TP_S_BN1_B, w.A1, 0, 512, GB, 0.0f, drop_p);
+  hipLaunchKernelGGL(tr_bn_act_kernel, blocks((long)GB * 512), dim3(256), 0, st, f1);
+  TR_RUN(gemm(st, w.A1, 512, 1, pr + ST_TP_S_FC2_W, 1, 512, w.H2, 512, pr + ST_TP_S_FC2_B, GB, 512, 512));
+  hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(8, G), dim3(256), 0, st, w.H2, B, 512, w.mean2, w.var2);
+  BnActArgs f2 = bnargs(w.H2, w.mean2, w.var2, ST_TP_S_BN2_G, ST_TP_S_BN2_B, w.A2, 1, 512, GB, 0.0f, drop_p);
+  hipLaunchKernelGGL(tr_bn_act_kernel, blocks((long)GB * 512), dim3(256), 0, st, f2);
+  TR_RUN(gemm(st, w.A2, 512, 1, pr + ST_TP_S_FC3_W, 1, 512, w.Z, 256, pr + ST_TP_S_FC3_B, GB, 256, 512));
+  const float* Pv = w.Z;  // simplest: the ori call's output is scored directly
+  BnActArgs fp{};
+  if (!simplest) {
+    TR_RUN(gemm(st, w.Z, 256, 1, pr + ST_TP_P_FC1_W, 1, 256, w.HP, 100, pr + ST_TP_P_FC1_B, B, 100, 256));
+    hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(2, 1), dim3(256), 0, st, w.HP, B, 100, w.pmean, w.pvar);
+    fp = bnargs(w.HP, w.pmean, w.pvar, ST_TP_P_BN_G, ST_TP_P_BN_B, w.Q, 0, 100, B, 0.2f, 0.0f);
+    hipLaunchKernelGGL(tr_bn_act_kernel, blocks((long)B * 100), dim3(256), 0, st, fp);
+    TR_RUN(gemm(st, w.Q, 100, 1, pr + ST_TP_P_FC2_W, 1, 100, w.P, 256, pr + ST_TP_P_FC2_B, B, 256, 100));
+    Pv = w.P;
+  }
+  hipLaunchKernelGGL(tr_score_kernel, dim3((B + 3) / 4), dim3(256), 0, st, Pv, w.Z, B, Kp, Kn, tau, w.S, w.lossrow, w.choice);
+  hipLaunchKernelGGL(tr_loss_kernel, dim3(1), dim3(256), 0, st, w.lossrow, B, Kp, (flags & ST_F_JUST_USE_ONE) ? 1 : 0, loss_out, w.sel);
+  ST_LAUNCH_CHECK();
+  if (choice_out) ST_HIP(hipMemcpyAsync(choice_out, w.choice, (size_t)Kp * B * 4, hipMemcpyDeviceToDevice, st));
+  // ---------------- backward ----------------
+  ST_HIP(hipMemsetAsync(grads, 0, (size_t)ST_TP_COUNT * 4, st));
+  // d loss / d P (and, simplest mode, d loss / d Z of the like / unlike calls: rows of w.dZ in call order)
+  hipLaunchKernelGGL(tr_dscore_kernel, dim3((B + 3) / 4), dim3(256), 0, st, Pv, w.Z, w.S, w.sel, B, Kp, Kn, tau, simplest ? 1 : 0,
+                     simplest ? w.dZ : w.dP);
+  ST_LAUNCH_CHECK();
+  if (!simplest) {
+    // Predictor: fc2 <- LeakyReLU <- BatchNorm <- fc1
+    TR_RUN(weight_grads(st, w, w.dP, w.Q, B, 256, 100, gr + ST_TP_P_FC2_W, gr + ST_TP_P_FC2_B));
+    TR_RUN(gemm(st, w.dP, 256, 1, pr + ST_TP_P_FC2_W, 100, 1, w.dQ, 100, nullptr, B, 100, 256));
+    BnActArgs bp = fp;
+    bp.dA = w.dQ; bp.sums = w.sums; bp.dH = w.dQ;
+    hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(2, 1), dim3(256), 0, st, bp);
+    hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)B * 100), dim3(256), 0, st, bp);
+    ST_HIP(hipMemcpyAsync(gr + ST_TP_P_BN_B, w.sums, 100 * 4, hipMemcpyDeviceToDevice, st));
+    ST_HIP(hipMemcpyAsync(gr + ST_TP_P_BN_G, w.sums + 100, 100 * 4, hipMemcpyDeviceToDevice, st));
+    TR_RUN(weight_grads(st, w, w.dQ, w.Z, B, 100, 256, gr + ST_TP_P_FC1_W, gr + ST_TP_P_FC1_B));
+    TR_RUN(gemm(st, w.dQ, 100, 1, pr + ST_TP_P_FC1_W, 256, 1, w.dZ, 256, nullptr, B, 256, 100));
+    hipLaunchKernelGGL(tr_bn_running_kernel, dim3(1), dim3(256), 0, st, w.pmean, w.pvar, 1, 100, B, bn + ST_TB_P_RM, bn + ST_TB_P_RV);
+  }
+  // SiameseNet over the Gb calls that carry gradient (the leading Gb*B rows of every activation buffer)
+  TR_RUN(weight_grads(st, w, w.dZ, w.A2, GbB, 256, 512, gr + ST_TP_S_FC3_W, gr + ST_TP_S_FC3_B));
+  TR_RUN(gemm(st, w.dZ, 256, 1, pr + ST_TP_S_FC3_W, 512, 1, w.d512a, 512, nullptr, GbB, 512, 256));
+  BnActArgs b2 = f2;
+  b2.rows = GbB; b2.dA = w.d512a; b2.sums = w.sums; b2.dH = w.d512a;
+  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(256), 0, st, b2);
+  hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)GbB * 512), dim3(256), 0, st, b2);
+  // d beta / d gamma: sum over the calls of sums[g][0] / sums[g][1]
+  hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums, Gb, 1024L, 512L, gr + ST_TP_S_BN2_B);
+  hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums + 512, Gb, 1024L, 512L, gr + ST_TP_S_BN2_G);
+  ST_LAUNCH_CHECK();
+  TR_RUN(weight_grads(st, w, w.d512a, w.A1, GbB, 512, 512, gr + ST_TP_S_FC2_W, gr + ST_TP_S_FC2_B));
+  TR_RUN(gemm(st, w.d512a, 512, 1, pr + ST_TP_S_FC2_W, 512, 1, w.d512b, 512, nullptr, GbB, 512, 512));
+  BnActArgs b1 = f1;
+  b1.rows = GbB; b1.dA = w.d512b; b1.sums = w.sums; b1.dH = w.d512b;
+  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(256), 0, st, b1);
+  hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)GbB * 512), dim3(256), 0, st, b1);
+  hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums, Gb, 1024L, 512L, gr + ST_TP_S_BN1_B);
+  hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums + 512, Gb, 1024L, 512L, gr + ST_TP_S_BN1_G);
+  ST_LAUNCH_CHECK();
+  TR_RUN(weight_grads(st, w, w.d512b, x, GbB, 512, 256, gr + ST_TP_S_FC1_W, gr + ST_TP_S_FC1_B));
+  // running statistics: every one of the G calls moved them, in call order
+  hipLaunchKernelGGL(tr_bn_running_kernel, dim3(2), dim3(256), 0, st, w.mean1, w.var1, G, 512, B, bn + ST_TB_S_RM1, bn + ST_TB_S_RV1);
+  hipLaunchKernelGGL(tr_bn_running_kernel, dim3(2), dim3(256), 0, st, w.mean2, w.var2, G, 512, B, bn + ST_TB_S_RM2, bn + ST_TB_S_RV2);
+  ST_LAUNCH_CHECK();
+#undef TR_RUN
+  (void)K;
+  return ST_OK;
+}
+
+extern "C" int st_adam_step(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int step, void* stream) {
+  ST_CHECK_ARG(n >= 0 && step >= 1 && beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "n=%lld step=%d beta=(%g, %g)",
+               (long long)n, step, beta1, beta2);
+  if (n == 0) return ST_OK;
+  ST_CHECK_ARG(params && grads && adam_m && adam_v, "NULL buffer");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(tr_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, adam_m, adam_v,
+                     (long)n, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}

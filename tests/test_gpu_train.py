@@ -1,0 +1,202 @@
+"""GPU parity tests of the scorer training step (st_scorer_train_step / st_adam_step) against
+(a) golden vectors produced by the reference's own torch modules + autograd + torch.optim.Adam
+(oracle/make_train_golden.py) and (b) the numpy restatement oracle/st_train_oracle.py on other shapes.
+Tolerances: fp32 path; gradients rtol 1e-4 (+ 2e-7 abs), loss 2e-6 relative on a single step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import st_train_oracle as T
+import train_common as TC
+
+pytestmark = pytest.mark.gpu
+GOLD = TC.GOLD
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from style_transfer_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _trainer(dev, ssd, psd, **kw):
+    from style_transfer_amd.train_scorer import ScorerTrainer, TrainConfig
+    return ScorerTrainer(ssd, psd, TrainConfig(**kw), dev)
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("tag,kw", TC.MODES)
+def test_train_steps_match_reference_golden(dev, tag, kw):
+    gd = np.load(os.path.join(GOLD, "scorer_train_%s.npz" % tag))
+    ssd, psd = TC.load_init()
+    shapes = TC.named(ssd, psd)
+    sl = TC.tensor_slices(shapes)
+    tr = _trainer(dev, ssd, psd, lr=float(gd["lr"]), **kw)
+    ori, like, unlike = (_dev(a, dev) for a in TC.golden_latents())
+    n = tr.params.numel()
+    idx = np.arange(0, n, TC.STRIDE)
+    for s in range(3):
+        masks = _dev(TC.golden_masks(gd, s).astype(np.uint8), dev)
+        loss, choice = tr.step(ori, like, unlike, keep_masks=masks)
+        torch.cuda.synchronize()
+        loss = float(loss.item())
+        assert abs(loss - gd["loss"][s]) <= (2e-6 if s == 0 else 2e-4) * abs(gd["loss"][s])
+        assert (choice.cpu().numpy() == gd["choice"][s]).mean() >= (1.0 if s == 0 else 0.995)
+        gf = tr.grads.cpu().numpy()
+        pf = tr.params.cpu().numpy()
+        noise = TC.noise_grad_tensors(gd, s)
+        for i, k in enumerate(TC.NAMES):
+            nrm = np.sqrt((gf[sl[k]].astype(np.float64) ** 2).sum())
+            if k in noise:
+                assert nrm < 1e-6
+                continue
+            assert abs(nrm - gd["grad_norms"][s][i]) <= (1e-5 if s == 0 else 0.1) * gd["grad_norms"][s][i], (s, k)
+            if s == 0:
+                sel = (idx >= sl[k].start) & (idx < sl[k].stop)
+                np.testing.assert_allclose(gf[idx[sel]], gd["grad"][0][sel], rtol=1e-4, atol=2e-7, err_msg=k)
+                ok = np.abs(pf[idx[sel]] - gd["param"][0][sel]) <= 1e-6
+                assert ok.mean() >= 0.999, (k, ok.mean())
+    s_sd, p_sd = tr.state_dicts()
+    for k in gd.files:
+        if not k.startswith("bn."):
+            continue
+        ours = (s_sd if k[3] == "s" else p_sd)[k[5:]].numpy()
+        if "tracked" in k:
+            assert int(ours) == int(gd[k])
+        else:
+            np.testing.assert_allclose(ours, gd[k], rtol=0, atol=5e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("B,Kp,Kn,kw", [(64, 10, 10, {}), (1024, 3, 5, {}), (1024, 3, 5, dict(simplest=True)),
+                                        (130, 1, 1, dict(just_use_one=True)), (2, 2, 3, {})])
+def test_every_gradient_element_matches_the_oracle(dev, B, Kp, Kn, kw):
+    """All 579 372 gradient elements, the loss, `choice` and the BatchNorm statistics against the numpy restatement,
+    with explicit masks; the large shapes go through the slab-split weight-gradient path (rows > 256)."""
+    rng = np.random.default_rng(B * 100 + Kp)
+    ssd, psd = TC.load_init()
+    # non-trivial BatchNorm affine parameters and running statistics
+    for sd in (ssd, psd):
+        for k in list(sd):
+            if k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+                sd[k] = (1 + 0.2 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+            elif "norm" in k and k.endswith(".bias"):
+                sd[k] = (0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+    ori = (rng.random((B, 256)) * 8).astype(np.float32)
+    like = (ori[None] + rng.standard_normal((Kp, B, 256))).astype(np.float32)
+    unlike = (rng.random((Kn, B, 256)) * 8).astype(np.float32)
+    masks = rng.random((1 + Kp + Kn, 2, B, 512)) >= 0.2
+    loss, choice, grads, stats = T.scorer_train_loss_and_grads(ssd, psd, ori, like, unlike, masks, **kw)
+    tr = _trainer(dev, ssd, psd, **kw)
+    ch = tr.loss_and_grads(_dev(ori, dev), _dev(like, dev), _dev(unlike, dev), keep_masks=_dev(masks.astype(np.uint8), dev))
+    torch.cuda.synchronize()
+    # B = 2 is BatchNorm's degenerate minimum (x_hat = +-1 up to eps: 1/sqrt(var + eps) amplifies rounding)
+    assert abs(float(tr.loss.item()) - loss) <= (5e-6 if B > 2 else 1e-4) * abs(loss)
+    if B > 2:      # with two rows BatchNorm maps everything to +-1 and ties in the scores are common
+        assert (ch.cpu().numpy() == choice).mean() >= 0.999
+    shapes = TC.named(ssd, psd)
+    sl = TC.tensor_slices(shapes)
+    gf = tr.grads.cpu().numpy()
+    assert np.isfinite(gf).all()
+    if B == 2:
+        return
+    for k in TC.NAMES:
+        ref = np.asarray(grads.get(k, np.zeros_like(shapes[k]))).ravel()
+        scale = np.abs(ref).max()
+        if scale < 1e-6:
+            assert np.abs(gf[sl[k]]).max() < 1e-6, k
+            continue
+        # Two fp32 summation orders over up to 9216 rows of terms that largely cancel (BatchNorm's backward makes every
+        # column of dH sum to zero): observed 6e-4 of the tensor's largest element.  On top of that a pre-activation
+        # within rounding of zero can fall on the other side of the ReLU (a handful among 4.7 M units), which moves
+        # single rows of a weight gradient by that unit's contribution: bound the bulk tightly and the outliers loosely.
+        d = np.abs(gf[sl[k]] - ref)
+        assert (d <= 1.5e-3 * scale).mean() >= 0.999, (k, (d <= 1.5e-3 * scale).mean())
+        assert d.max() <= 3e-2 * scale, (k, d.max(), scale)
+        assert np.sqrt((d.astype(np.float64) ** 2).sum()) <= 2e-3 * np.sqrt((ref.astype(np.float64) ** 2).sum()), k
+    s_sd, p_sd = tr.state_dicts()
+    for k, v in stats.items():
+        if "tracked" in k:
+            continue
+        ours = (s_sd if k[0] == "s" else p_sd)[k[2:]].numpy()
+        np.testing.assert_allclose(ours, v, rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def _hash_keep(seed, G, B, N=512, drop_p=0.2):
+    """numpy restatement of tr_keep (csrc/st_train.hip) -> bool [G,2,B,N]"""
+    idx = np.arange(G * 2 * B * N, dtype=np.uint64) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * idx
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(drop_p)).reshape(G, 2, B, N)
+
+
+def test_hashed_dropout_is_consistent_between_forward_and_backward(dev):
+    """Without explicit masks the keep decision is a hash of (seed, element): the oracle fed with the same hash
+    reproduces loss and gradients, about 80 % of the units are kept, and another seed gives another mask."""
+    ssd, psd = TC.load_init()
+    ori, like, unlike = TC.golden_latents()
+    tr = _trainer(dev, ssd, psd)
+    seed = 0x1234567
+    keep = _hash_keep(seed, 21, 64)
+    assert abs(keep.mean() - 0.8) < 0.005
+    loss, _, grads, _ = T.scorer_train_loss_and_grads(ssd, psd, ori, like, unlike, keep)
+    tr.loss_and_grads(_dev(ori, dev), _dev(like, dev), _dev(unlike, dev), seed=seed)
+    torch.cuda.synchronize()
+    assert abs(float(tr.loss.item()) - loss) <= 5e-6 * abs(loss)
+    shapes = TC.named(ssd, psd)
+    gf = tr.grads.cpu().numpy()
+    ref = TC.flat(grads, shapes)
+    assert np.abs(gf - ref).max() <= 1e-4 * np.abs(ref).max()
+    l1 = float(tr.loss.item())
+    tr.loss_and_grads(_dev(ori, dev), _dev(like, dev), _dev(unlike, dev), seed=seed + 1)
+    assert abs(float(tr.loss.item()) - l1) > 1e-4
+
+
+def test_train_contrastive_learns_and_its_checkpoint_drives_the_attack_kernels(dev, tmp_path):
+    """A few epochs on the 64 golden records: the summed epoch loss falls, accuracy rises; the saved
+    siamese_model_params.pkl / predictor_net_params.pkl load (weights_only) into the eval-mode scorer kernels."""
+    from style_transfer_amd.train_scorer import fresh_state_dicts, train_contrastive
+    from style_transfer_amd import weights as W, ops
+    g = np.load(os.path.join(GOLD, "attack_notnll.npz"))
+    ssd, psd = fresh_state_dicts(seed=3)
+    tr = _trainer(dev, {k: v.numpy() for k, v in ssd.items()}, {k: v.numpy() for k, v in psd.items()})
+    lines = []
+    hist = train_contrastive(tr, _dev(g["init_latent"], dev), _dev(g["like_latent"], dev), _dev(g["unlike_latent"], dev),
+                             batch_size=32, epochs=12, log=lines.append, save_path=str(tmp_path))
+    assert hist[-1][0] < 0.7 * hist[0][0] and hist[-1][1] > hist[0][1]
+    assert lines[0].endswith("Training Siamese by lr=0.003" + "+" * 20) and lines[-1].startswith("Epoch Loss=")
+    s_sd = torch.load(tmp_path / "siamese_model_params.pkl", weights_only=True)
+    p_sd = torch.load(tmp_path / "predictor_net_params.pkl", weights_only=True)
+    assert int(s_sd["norm1.num_batches_tracked"]) == 12 * 2 * 21 and int(p_sd["norm1.num_batches_tracked"]) == 24
+    sw = W.ScorerWeights(s_sd, p_sd, dev)
+    z = ops.scorer_embed(sw, _dev(g["init_latent"], dev), unit=False)
+    ref = T_eval(s_sd, g["init_latent"])
+    np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=2e-3, atol=2e-4)
+
+
+def T_eval(s_sd, x):
+    import st_oracle as O
+    return O.siamese_forward({k: v.numpy() for k, v in s_sd.items()}, x)
+
+
+def test_argument_errors(dev):
+    from style_transfer_amd._lib import StError
+    ssd, psd = TC.load_init()
+    tr = _trainer(dev, ssd, psd)
+    x = torch.zeros(1, 256, device=dev)
+    with pytest.raises(StError, match="B >= 2"):
+        tr.loss_and_grads(x, torch.zeros(1, 1, 256, device=dev), torch.zeros(1, 1, 256, device=dev))
+    with pytest.raises(StError, match="Kn"):
+        tr.loss_and_grads(torch.zeros(4, 256, device=dev), torch.zeros(1, 4, 256, device=dev), torch.zeros(0, 4, 256, device=dev))

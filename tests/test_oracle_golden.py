@@ -115,3 +115,39 @@ def test_fgim_oracle_vs_reference(ae_sd, id_to_word):
         ref_texts = [lines[i] for i in range(3, len(lines), 3)]        # gold / (epsilon, It, text) x 9
         assert texts == ref_texts and texts[-1] == ret
         assert lines[2] == "| It {:2d} | dis model pred {:5.4f} |".format(5, float(pred[s]))
+
+
+# ---- scorer training step: numpy restatement vs the reference's torch autograd + Adam ----
+@pytest.mark.parametrize("tag,kw", [("nll", {}), ("simplest", dict(simplest=True)), ("nll_one", dict(just_use_one=True))])
+def test_scorer_train_step_oracle_vs_reference(tag, kw):
+    import train_common as TC
+    gd = np.load(os.path.join(GOLD, "scorer_train_%s.npz" % tag))
+    steps = TC.oracle_steps(kw, gd, 3, float(gd["lr"]))
+    shapes = TC.named(*TC.load_init())
+    sl = TC.tensor_slices(shapes)
+    idx = np.arange(0, sum(int(np.prod(shapes[k].shape)) for k in TC.NAMES), TC.STRIDE)
+    for s, st in enumerate(steps):
+        assert abs(st["loss"] - gd["loss"][s]) <= (2e-6 if s == 0 else 2e-4) * abs(gd["loss"][s])
+        assert (st["choice"] == gd["choice"][s]).mean() >= (1.0 if s == 0 else 0.995)
+        gf = TC.flat(st["grads"], shapes)
+        noise = TC.noise_grad_tensors(gd, s)
+        for i, k in enumerate(TC.NAMES):
+            nrm = np.sqrt((gf[sl[k]].astype(np.float64) ** 2).sum())
+            if k in noise:
+                assert nrm < 1e-6                      # ours is rounding noise as well
+                continue
+            # per-tensor norm: every step (later steps see Adam's amplification of ~1e-8 gradients, see train_common)
+            assert abs(nrm - gd["grad_norms"][s][i]) <= (1e-5 if s == 0 else 0.1) * gd["grad_norms"][s][i], (s, k)
+            if s == 0:
+                sel = (idx >= sl[k].start) & (idx < sl[k].stop)
+                np.testing.assert_allclose(gf[idx[sel]], gd["grad"][0][sel], rtol=1e-4, atol=2e-7, err_msg=k)
+                # one Adam step: +-lr moves; elements with |g| ~ eps = 1e-8 depend on the last bit of g
+                pf = st["params"][k].ravel()[idx[sel] - sl[k].start]
+                ok = np.abs(pf - gd["param"][0][sel]) <= 1e-6
+                assert ok.mean() >= 0.999, (k, ok.mean())
+    # BatchNorm statistics after 3 x 21 (resp. 3 x 1) updates; the noise-driven bias drift enters running_mean
+    for k in gd.files:
+        if k.startswith("bn.") and "tracked" not in k:
+            np.testing.assert_allclose(steps[-1]["stats"][k[3:]], gd[k], rtol=0, atol=5e-3, err_msg=k)
+        elif k.startswith("bn."):
+            assert int(gd[k]) in (0, 3, 63)
