@@ -95,6 +95,10 @@ def build_parser():
                    help='autoencoder matrix products: f16x3 = f16 hi+lo split operands, 3 MFMA products per term, f32 '
                         'accumulate (f32-grade results, default); f32 = exact f32 MFMA (~2x slower end to end)')
     g.add_argument('--quiet', action='store_true', help='do not echo log records on stdout')
+    g.add_argument('--siamese_epochs', type=int, default=50, help='epochs of scorer training without --attack (main.py:490)')
+    g.add_argument('--train_files', type=str, default='neg10_pos10_train0.json,neg10_pos10_train1.json',
+                   help='training records under --data_path (siamese_contrastive.py:234-239; same schema as the test files)')
+    g.add_argument('--init_seed', type=int, default=None, help='seed of the fresh SiameseNet / Predictor weights')
     return p
 
 
@@ -138,12 +142,53 @@ def gather_results(res, world, backend_device):
     return AttackResult(**out)
 
 
+def train_scorer_main(args, ae, vocab_size, data_path, save_path, device, rank, world, log):
+    """`python main.py` without --attack (main.py:488-490): train SiameseNet + Predictor on the frozen AE's latents
+    and write siamese_model_params.pkl / predictor_net_params.pkl under save_path after every epoch."""
+    import torch
+    from .attack import AttackConfig, AttackRunner
+    from .data import AttackSet
+    from .train_scorer import ScorerTrainer, TrainConfig, fresh_state_dicts, train_contrastive
+    files = [os.path.join(data_path, f) for f in args.train_files.split(',')]
+    say = log if rank == 0 else (lambda *_: None)
+    say('Loading train Dataset, Shuffle=True')
+    say('ori_file_list = {}'.format(files))
+    if rank == 0:
+        print('Random Seed is set to 234')
+    data = AttackSet.from_json(files, vocab_size, args.id_unk, args.max_sequence_length, args.pos_num, args.neg_num)
+    if data.n_pos < 1 or data.n_neg < 1:
+        raise ValueError("training needs at least one like and one unlike sentence per record (NLL form, siamese_contrastive.py:438-446)")
+    runner = AttackRunner(ae, None, AttackConfig.from_namespace(args), device)
+    ori, like, unlike = [], [], []
+    CH = 8192                                    # records per encoder pass (21 sentences each)
+    for c0 in range(0, len(data), CH):
+        sub = data.subset(list(range(c0, min(len(data), c0 + CH))))
+        lat = runner.encode_prepared(runner.prepare(sub))
+        n = len(sub)
+        ori.append(lat[:n].clone())
+        like.append(lat[n:n + n * data.n_pos].view(n, data.n_pos, 256).clone())
+        unlike.append(lat[n + n * data.n_pos:].view(n, data.n_neg, 256).clone())
+    ori, like, unlike = torch.cat(ori), torch.cat(like), torch.cat(unlike)
+    s_sd, p_sd = fresh_state_dicts(args.init_seed)
+    if world > 1:                                # every rank starts from rank 0's weights
+        import torch.distributed as dist
+        for sd in (s_sd, p_sd):
+            for k in sorted(sd):
+                t = sd[k].to(device)
+                dist.broadcast(t, 0)
+                sd[k] = t.cpu()
+    trainer = ScorerTrainer(s_sd, p_sd, TrainConfig(lr=args.train_siamese_lr, tau=args.tau, simplest=args.simplest_siamese,
+                                                    just_use_one=args.just_use_one), device)
+    os.makedirs(save_path, exist_ok=True)
+    train_contrastive(trainer, ori, like, unlike, batch_size=args.batch_size, epochs=args.siamese_epochs, log=say,
+                      rank=rank, world=world, save_path=save_path)
+    return 0
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     args.if_load_from_checkpoint = True        # main.py:130-131
     args.checkpoint_name = "origin"
-    if not args.attack:
-        sys.exit("only the --attack path is implemented (training is out of scope, SURVEY.md §8)")
     import torch
     from . import weights as W
     from .attack import AttackConfig, AttackRunner, concat_results, write_attack_log
@@ -198,6 +243,16 @@ def main(argv=None):
     ae = W.AEWeights(ae_sd, device, max_len=args.max_sequence_length, gemm_format=args.gemm_format)
     if ae.vocab != vocab_size:
         raise ValueError("checkpoint vocabulary %d != word_to_id vocabulary %d" % (ae.vocab, vocab_size))
+    if not args.attack:
+        # main.py:488-490: train_contrastive(siamese_net, predictor_net, ae_model, args, 50) on fresh nets
+        rc = train_scorer_main(args, ae, vocab_size, data_path, save_path, device, rank, world, log)
+        if rank == 0:
+            log.close()
+            print('Done')
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return rc
     # load_siamese (siamese_contrastive.py:1565-1587): exit(0) when a file is missing
     sp, pp = os.path.join(save_path, 'siamese_model_params.pkl'), os.path.join(save_path, 'predictor_net_params.pkl')
     # the same state-dicts re-saved as safetensors (tests/golden) are accepted when the .pkl is absent

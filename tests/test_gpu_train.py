@@ -200,3 +200,26 @@ def test_argument_errors(dev):
         tr.loss_and_grads(x, torch.zeros(1, 1, 256, device=dev), torch.zeros(1, 1, 256, device=dev))
     with pytest.raises(StError, match="Kn"):
         tr.loss_and_grads(torch.zeros(4, 256, device=dev), torch.zeros(1, 4, 256, device=dev), torch.zeros(0, 4, 256, device=dev))
+
+
+def test_cli_trains_the_scorer_then_attacks_with_it(dev, tmp_path):
+    """`main.py` without --attack trains (main.py:488-490) and leaves the two checkpoints `--attack` loads
+    (siamese_contrastive.py:1556-1587).  Training records: the 1000 yelp test records (the train files are not shipped)."""
+    from style_transfer_amd import main as M
+    save = str(tmp_path) + "/"
+    common = ["--save_path", save, "--data_path", os.path.join(GOLD, "yelp") + "/", "--ae_checkpoint",
+              os.path.join(GOLD, "surrogate_ae_yelp.safetensors"), "--quiet"]
+    tlog = tmp_path / "train_log"
+    rc = M.main(["--train_files", "neg10_pos10_test0.json,neg10_pos10_test1.json", "--siamese_epochs", "3", "--init_seed", "7",
+                 "--log_file", str(tlog)] + common)
+    assert rc == 0
+    lines = open(tlog).read().splitlines()
+    losses = [float(l.split("Epoch Loss=")[1]) for l in lines if "Epoch Loss=" in l]
+    assert len(losses) == 3 and losses[2] < losses[0]          # 7 batches of 128 per epoch
+    assert any("--- Attack: False" in l for l in lines) and any("Training Siamese by lr=0.003" in l for l in lines)
+    assert os.path.exists(save + "siamese_model_params.pkl") and os.path.exists(save + "predictor_net_params.pkl")
+    alog = tmp_path / "attack_log"
+    rc = M.main(["--attack", "--not_nll", "--pos_victim_lr=0.2", "--neg_victim_lr=0.2", "--limit", "2", "--log_file", str(alog)] + common)
+    assert rc == 0
+    text = open(alog).read()
+    assert text.count("Sentence Pair.") == 4 and "iteration.0," in text

@@ -209,3 +209,97 @@ def test_dance_digest_matches_reference_definition():
     # NLL: per positive i the argmax of [pos_i, neg_0, neg_1, neg_2]
     assert dance_digest(scores, 3, False) == [[1], [1], [1]]
     assert dance_digest(np.array([5.0, 0.0, 1.0, 2.0], np.float32), 1, False) == [[0]]
+
+
+TRAIN_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle")); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import st_train_oracle as T
+import train_common as TC
+from style_transfer_amd.train_scorer import ScorerTrainer, TrainConfig, train_contrastive, epoch_order, PARAM_ORDER, PARAM_SHAPES
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+
+class OracleTrainer(ScorerTrainer):
+    # the HIP calls replaced by the numpy restatement: this test is about the host loop and the collectives
+    def _sds(self):
+        s, p = self.state_dicts()
+        return {k: v.numpy() for k, v in s.items()}, {k: v.numpy() for k, v in p.items()}
+    def loss_and_grads(self, ori, like, unlike, keep_masks=None, seed=None):
+        ssd, psd = self._sds()
+        loss, choice, grads, stats = T.scorer_train_loss_and_grads(ssd, psd, ori.numpy(), like.numpy(), unlike.numpy(), None)
+        shapes = TC.named(ssd, psd)
+        self.grads.copy_(torch.from_numpy(TC.flat(grads, shapes)))
+        self.loss[0] = float(loss)
+        bn = [stats[n + "." + k] for n, k, _ in __import__("style_transfer_amd.train_scorer", fromlist=["BN_ORDER"]).BN_ORDER]
+        self.bn.copy_(torch.from_numpy(np.concatenate(bn)))
+        return torch.from_numpy(choice.astype(np.int32))
+    def adam(self):
+        self.step_no += 1
+        p, m, v = T.adam_update(self.params.numpy(), self.grads.numpy(), self.m.numpy(), self.v.numpy(), self.step_no, self.cfg.lr)
+        self.params.copy_(torch.from_numpy(p)); self.m.copy_(torch.from_numpy(m)); self.v.copy_(torch.from_numpy(v))
+
+ssd, psd = TC.load_init()
+g = np.load(os.path.join(TC.GOLD, "attack_notnll.npz"))
+ori, like, unlike = (torch.from_numpy(g[k].copy()) for k in ("init_latent", "like_latent", "unlike_latent"))
+tr = OracleTrainer(ssd, psd, TrainConfig(drop_p=0.0), "cpu")
+lines = []
+hist = train_contrastive(tr, ori, like, unlike, batch_size=32, epochs=2, log=lines.append, rank=rank, world=world)
+# every rank holds the same parameters after the all-reduced steps
+gathered = [torch.zeros_like(tr.params) for _ in range(world)]
+dist.all_gather(gathered, tr.params)
+assert all(torch.equal(gathered[0], t) for t in gathered)
+# single-process emulation of the same data-parallel schedule: per-half-batch gradients averaged
+ref = OracleTrainer(ssd, psd, TrainConfig(drop_p=0.0), "cpu")
+for epoch in range(2):
+    for rec in epoch_order(64, 32):
+        gs = []
+        for r in range(world):
+            sel = torch.as_tensor(rec[r * 16:(r + 1) * 16])
+            ref.loss_and_grads(ori[sel], like[sel].transpose(0, 1), unlike[sel].transpose(0, 1))
+            gs.append(ref.grads.clone())
+        ref.grads.copy_(sum(gs) / world)
+        ref.adam()
+# elementwise Adam turns last-bit differences of ~1e-8 gradients into +-lr moves (train_common.noise_grad_tensors):
+# compare the tensors that carry real gradient
+off = 0
+for (net, name), shape in zip(PARAM_ORDER, PARAM_SHAPES):
+    n = int(np.prod(shape))
+    if not (name.endswith("bias") and name.startswith("fc")):
+        d = (tr.params[off:off + n] - ref.params[off:off + n]).abs()
+        assert float((d <= 1e-5).float().mean()) >= 0.999, (net, name, float(d.max()))
+    off += n
+assert hist[1][0] < hist[0][0] and lines[-1].startswith("Epoch Loss=")
+dist.destroy_process_group()
+open(os.path.join(%(out)r, "ok%%d" %% rank), "w").write("ok")
+"""
+
+
+def test_two_rank_data_parallel_scorer_training(tmp_path):
+    """train_contrastive on 2 ranks (gloo): each rank takes half of every batch, gradients are averaged with one
+    all-reduce of the flat vector, both ranks end with identical parameters that match a single-process emulation."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    script = tmp_path / "w.py"
+    script.write_text(TRAIN_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_epoch_order_is_the_reference_shuffle():
+    """random.seed(234); random.shuffle(list) (siamese_contrastive.py:276-290, data.py:403-408): same permutation for
+    any list of that length, batches of int(n / batch_size) * batch_size records, remainder dropped."""
+    import random
+    from style_transfer_amd.train_scorer import epoch_order
+    items = ["r%d" % i for i in range(1000)]
+    random.seed(234)
+    random.shuffle(items)
+    batches = epoch_order(1000, 128)
+    assert len(batches) == 7 and all(len(b) == 128 for b in batches)
+    assert ["r%d" % i for b in batches for i in b] == items[:896]
