@@ -154,6 +154,8 @@ class AttackRunner:
         if c.not_nll and kp != kn and kp and kn:
             # the reference adds pos_loss [K+] to neg_loss [K-] (siamese_contrastive.py:429): a size-mismatch error
             raise ValueError("--not_nll needs pos_num == neg_num (got %d and %d), as in the reference" % (kp, kn))
+        if B == 0:
+            return empty_result(c, kp, kn)
         tm = {}
         t0 = time.perf_counter()
         lat_all = self.encode_prepared(prep)
@@ -317,6 +319,17 @@ class AttackRunner:
             res.trace["unlike_latent"] = unlike_lat.view(B, kn, 256).cpu().numpy() if kn else None
         res.timing = tm
         return res
+
+
+def empty_result(cfg: AttackConfig, kp: int, kn: int) -> AttackResult:
+    """Records of zero sentences with the shapes a non-empty run would have (an empty shard of a multi-GPU run:
+    every rank must present the same fields to the gather)."""
+    T = cfg.max_sequence_length - 1
+    I = 2 if cfg.dance else cfg.attack_max_iter
+    ids = lambda k: np.zeros((0, k, T), np.int32) if (cfg.log_decodes and k) else None
+    return AttackResult(np.zeros(0, np.int32), np.zeros((0, T), np.int32), np.zeros((0, I, T), np.int32),
+                        np.zeros((0, I), np.uint8), ids(kp), ids(kn), final_latent=np.zeros((0, 256), np.float32),
+                        timing=dict(units=0, setup_s=0.0, loop_s=0.0))
 
 
 def concat_results(parts):

@@ -191,7 +191,7 @@ def main(argv=None):
     args.checkpoint_name = "origin"
     import torch
     from . import weights as W
-    from .attack import AttackConfig, AttackRunner, concat_results, write_attack_log
+    from .attack import AttackConfig, AttackRunner, concat_results, empty_result, write_attack_log
     from .data import AttackSet, load_word_dict_info
     from .logfmt import LogWriter, headline
 
@@ -294,7 +294,7 @@ def main(argv=None):
     for b0 in range(lo, hi, args.attack_batch):
         idx = list(range(b0, min(hi, b0 + args.attack_batch)))
         parts.append(runner.run_batch(data.subset(idx), idx))
-    res = concat_results(parts) if parts else None
+    res = concat_results(parts) if parts else empty_result(cfg, data.n_pos, data.n_neg)   # more ranks than sentences
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     if world > 1:

@@ -335,3 +335,48 @@ def test_attack_amazon_matches_reference(scorer_sd_torch, fmt):
     # encoder latents of all 21 sentences per origin (like/unlike up to 31 tokens)
     np.testing.assert_allclose(res.trace["like_latent"], g["like_latent"], rtol=0, atol=2e-4 * np.abs(g["like_latent"]).max())
     np.testing.assert_allclose(res.trace["unlike_latent"], g["unlike_latent"], rtol=0, atol=2e-4 * np.abs(g["unlike_latent"]).max())
+
+
+def test_edge_cases_against_the_oracle(env, ae_sd, scorer_sd, id_to_word):
+    """Empty batch; a batch of one; one-token and over-long (truncated to max_sequence_length - 1 = 59 tokens,
+    data.py:119-152) sentences; the smallest reference sets (one like + one unlike) with ragged lengths.  Checked
+    against the numpy restatement of contrastive_attack_one run sentence by sentence."""
+    import st_oracle as O
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet, _clip
+    cfg = AttackConfig(log_decodes=False, want_trace=True, not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2)
+    r = AttackRunner(env["ae"], env["scorer"], cfg, env["dev"])
+    r.set_vocab(id_to_word)
+    empty = r.run_batch(AttackSet([], [], []), [])
+    assert len(empty.n_iter) == 0 and empty.iter_ids.shape[0] == 0
+    rng = np.random.default_rng(5)
+    V = env["V"]
+    tok = lambda n: [int(t) for t in rng.integers(4, V, n)]
+    clip = lambda s: _clip(s, V, 1, 60)
+    origin = [clip(tok(1)), clip(tok(70)), clip(tok(9)), clip(tok(15) + [V + 5])]     # last: an out-of-vocabulary id -> UNK
+    like = [[clip(tok(1))], [clip(tok(16))], [clip(tok(64))], [clip(tok(7))]]
+    unlike = [[clip(tok(12))], [clip(tok(1))], [clip(tok(3))], [clip(tok(59))]]
+    assert len(origin[1]) == 59 and origin[3][-1] == 1
+    data = AttackSet(origin, like, unlike)
+    res = r.run_batch(data, list(range(4)))
+    one = r.run_batch(data.subset([2]), [0])                 # a batch of one sentence gives the same record
+    assert np.array_equal(one.iter_ids[0], res.iter_ids[2]) and int(one.n_iter[0]) == int(res.n_iter[2])
+    ssd, psd = scorer_sd
+    for s in range(4):
+        enc = lambda sent: O.encode_latent(ae_sd, np.asarray([sent], np.int64))
+        lines, trace = [], []
+        O.attack_one(ae_sd, ssd, psd, enc(origin[s]), enc(like[s][0]), enc(unlike[s][0]), 0.2, id_to_word, lines.append,
+                     not_nll=True, trace=trace)
+        n = len(trace)
+        ok = True
+        for it in range(n):
+            lat = res.trace["latent"][s, it]
+            if np.abs(lat - trace[it]["latent"][0]).max() > LAT_RTOL * np.abs(trace[it]["latent"]).max():
+                ok = False      # an Adam first-step sign flip of a ~0 gradient coordinate (DESIGN §2): rare, tolerated once
+                break
+            e = text_end(trace[it]["ids"])
+            if not np.array_equal(res.trace["ids"][s, it][:e + 1], trace[it]["ids"][:e + 1]):
+                ok = False
+                break
+        assert ok, ("edge case diverged from the oracle", s)
+        assert int(res.n_iter[s]) == n

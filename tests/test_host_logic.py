@@ -125,17 +125,21 @@ from style_transfer_amd.main import gather_results, shard_range
 from style_transfer_amd.attack import AttackResult
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-S, I, T = 11, 18, 59
+from style_transfer_amd.attack import AttackConfig, empty_result
+I, T = 18, 59
 rng = np.random.default_rng(0)
-full = AttackResult(rng.integers(0, 19, S).astype(np.int32), rng.integers(0, 9000, (S, T)).astype(np.int32),
-                    rng.integers(0, 9000, (S, I, T)).astype(np.int32), rng.integers(0, 2, (S, I)).astype(np.uint8),
-                    rng.integers(0, 9000, (S, 10, T)).astype(np.int32), None)
-lo, hi = shard_range(S, rank, world)
-mine = AttackResult(full.n_iter[lo:hi], full.init_ids[lo:hi], full.iter_ids[lo:hi], full.changed[lo:hi], full.like_ids[lo:hi], None)
-got = gather_results(mine, world, torch.device("cpu"))
-for f in ("n_iter", "init_ids", "iter_ids", "changed", "like_ids"):
-    assert np.array_equal(getattr(got, f), getattr(full, f)), f
-assert got.unlike_ids is None
+for S in (11, 1):          # S = 1: rank 1 holds an empty shard (more ranks than sentences)
+    full = AttackResult(rng.integers(0, 19, S).astype(np.int32), rng.integers(0, 9000, (S, T)).astype(np.int32),
+                        rng.integers(0, 9000, (S, I, T)).astype(np.int32), rng.integers(0, 2, (S, I)).astype(np.uint8),
+                        rng.integers(0, 9000, (S, 10, T)).astype(np.int32), None)
+    lo, hi = shard_range(S, rank, world)
+    mine = AttackResult(full.n_iter[lo:hi], full.init_ids[lo:hi], full.iter_ids[lo:hi], full.changed[lo:hi], full.like_ids[lo:hi], None)
+    if lo == hi:
+        mine = empty_result(AttackConfig(log_decodes=True), 10, 0)
+    got = gather_results(mine, world, torch.device("cpu"))
+    for f in ("n_iter", "init_ids", "iter_ids", "changed", "like_ids"):
+        assert np.array_equal(getattr(got, f), getattr(full, f)), f
+    assert got.unlike_ids is None
 dist.destroy_process_group()
 open(os.path.join(%(out)r, "ok%%d" %% rank), "w").write("ok")
 """
