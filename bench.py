@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-decode", default="11,7", help="edit iterations decoded per round: an int or a schedule like 9,5,4")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--distinct-batches", action="store_true",
+                    help="a different synthetic batch for every warm-up and timed step (BASELINE config 4: --steps 31 = 1 M distinct "
+                         "origins per GPU), all resident in HBM before the timed region; default: one batch reused")
     ap.add_argument("--no-f32-reference-run", action="store_true",
                     help="skip the short exact-f32-format run that is reported beside the f16x3 value")
     ap.add_argument("--gemm-format", default="f16x3", choices=["f16x3", "f32"],
@@ -124,6 +127,14 @@ def main():
         counts = load_word_counts(os.path.join(GOLD, a.shape, "word_to_id.txt"), ae.vocab) if a.tokens == "zipf" else None
         data = AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank, word_counts=counts)
     prep = runner.prepare(data)                       # tokens resident in HBM before the timed region
+    preps = [prep] * (a.warmup + a.steps)
+    if a.distinct_batches:
+        if a.tokens == "real":
+            raise SystemExit("--distinct-batches needs synthetic tokens")
+        for k in range(1, a.warmup + a.steps):
+            preps[k] = runner.prepare(AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank + 7919 * k, word_counts=counts))
+            if rank == 0 and k % 4 == 0:
+                print("[bench] generated batch %d of %d" % (k + 1, a.warmup + a.steps), file=sys.stderr, flush=True)
     gidx = torch.arange(B, device=dev) % 1000
 
     def sync():
@@ -132,15 +143,15 @@ def main():
         torch.cuda.synchronize(dev)
 
     L = _lib.lib()
-    for _ in range(a.warmup):
-        runner.run_prepared(prep, gidx, fetch=False)
+    for k in range(a.warmup):
+        runner.run_prepared(preps[k], gidx, fetch=False)
     sync()
     L.st_profile_enable(_lib.ST_PROF_HALF_LAYER if a.gemm_format == "f16x3" else _lib.ST_PROF_GENERATOR)
     units = 0
     setup_s = loop_s = 0.0
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        r = runner.run_prepared(prep, gidx, fetch=False)
+    for k in range(a.steps):
+        r = runner.run_prepared(preps[a.warmup + k], gidx, fetch=False)
         units += r.timing["units"]
         setup_s += r.timing["setup_s"]
         loop_s += r.timing["loop_s"]
@@ -205,7 +216,7 @@ def main():
                                    % (a.shape, {"zipf": "unigram/Zipfian from word_to_id.txt counts", "uniform": "uniform in [4,V)",
                                                 "real": "the real yelp test set tiled"}[a.tokens], B,
                                       "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS"),
-                       "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
+                       "distinct_batches": bool(a.distinct_batches), "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
                        "mean_edit_iterations_per_sentence": n_iter_mean,
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
                        "iters_per_decode": cfg.iters_per_decode, "gemm_format": a.gemm_format,
