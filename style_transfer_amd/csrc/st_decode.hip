@@ -290,6 +290,7 @@ struct DecodeWs {
 };
 #define ST_GEN_SPLITS 16        /* max column splits of the generator (partials per row) */
 #define ST_SCREEN_MIN_ROWS 2048 /* below this the two extra launches of the screened argmax cost more than they save */
+#define ST_SYNC_RELAX_ROWS 1024  /* below this many live rows the host reads the live count every 4th step only */
 #define ST_GEN_SPLITS_SMALL 96  /* ... when few rows are live: the late steps are latency-bound on streaming W */
 
 static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base) {
@@ -386,6 +387,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   int n_bound = B;
   int cur = 0;
   int steps = 0;
+  int since_sync = 0;
   static const bool trace_steps = getenv("ST_TRACE_STEPS") != nullptr;  // debug: live rows per step on stderr
   if (trace_steps) fprintf(stderr, "[st_decode] B=%d live:", B);
   for (int pos = 0; pos < T && n_bound > 0; ++pos) {
@@ -481,7 +483,14 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_end(&pp, st));
     cur ^= 1;
     ++steps;
-    if (early && ((pos + 1) % sync_every == 0) && pos + 1 < T) {
+    // The host reads the live count to size the next grids.  With few rows left (the straggler tail: a handful of
+    // decodes that never emit EOS) a step is ~0.25 ms and the read-back costs a ~50 us bubble, so it is done every
+    // 4th step there: the kernels take n from n_dev and workgroups past it exit at once, so a stale (larger) bound
+    // changes no result; the price is at most 3 empty steps after the last row has finished.
+    ++since_sync;
+    const int every = n_bound < ST_SYNC_RELAX_ROWS ? (sync_every > 4 ? sync_every : 4) : sync_every;
+    if (early && since_sync >= every && pos + 1 < T) {
+      since_sync = 0;
       int live = 0;
       ST_HIP(hipMemcpyAsync(&live, ws.cnt + cur, sizeof(int), hipMemcpyDeviceToHost, st));
       ST_HIP(hipStreamSynchronize(st));
