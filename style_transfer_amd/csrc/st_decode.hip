@@ -286,6 +286,7 @@ struct DecodeWs {
   int* idx[2];     // [B]
   int* amb;        // [B] live rows the screening pass could not decide
   int* cnt;        // [0],[1]: live counts (ping-pong), [2]: ambiguous rows of the current step
+  float* slab;     // [d_ff/256][64][256] split-K partials of feed_forward.w_2 when one panel of rows is left
   size_t total;
 };
 #define ST_GEN_SPLITS 16        /* max column splits of the generator (partials per row) */
@@ -313,6 +314,7 @@ static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base)
   ws.idx[1] = (int*)take((size_t)B * 4);
   ws.amb = (int*)take((size_t)B * 4);
   ws.cnt = (int*)take(256);
+  ws.slab = (float*)take((size_t)(w->d_ff / 256) * 64 * 256 * 4);
   ws.total = off;
   return ws;
 }
@@ -444,7 +446,18 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       f2.fmt = w->gemm_format; f2.range_flag = ws.cnt + 3;
       f2.X = ws.h; f2.n_dev = n_dev; f2.n_host = n_bound; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256;
       f2.out = ws.x; f2.ldo = 256; f2.resid = ws.x;
-      ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, n_bound, st));
+      if (n_bound <= 64 && w->d_ff > 256) {
+        // one panel left (the straggler tail): a single workgroup would stream all of W2 (1 MiB) by itself, ~44 us;
+        // one workgroup per 256-wide K chunk + a combine over the live rows takes a third of that
+        const int ks = w->d_ff / 256;
+        f2.out = ws.slab;
+        ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, n_bound, st, ks));
+        hipLaunchKernelGGL(slab_reduce_rows_kernel<0>, dim3((n_bound * 64 + 255) / 256), dim3(256), 0, st, ws.slab, ks,
+                           (size_t)n_bound * 256, ws.x, n_dev, 256);
+        ST_LAUNCH_CHECK();
+      } else {
+        ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, n_bound, st));
+      }
     }
     GemmArgs gg = {};
     gg.fmt = w->gemm_format; gg.range_flag = ws.cnt + 3;

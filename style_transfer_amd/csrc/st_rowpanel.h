@@ -408,7 +408,9 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
   constexpr int F = H ? 2 : 1;      // fragments per step
   const int K = a.K, nchunk = K >> 8, spb = nchunk * SPC;  // steps per column block
   // split-K (gridDim.y > 1): this workgroup sums chunks [c_begin, c_end) into slab blockIdx.y of `out`
-  // ([gridDim.y][n_host][ldo]; summed by slab_reduce_kernel); the caller passes bias == resid == null
+  // ([gridDim.y][n_host][ldo]; summed by slab_reduce_kernel / slab_reduce_rows_kernel); bias and residual enter
+  // through slab 0 only
+  const bool first = blockIdx.y == 0;
   const int cps = (nchunk + gridDim.y - 1) / gridDim.y;
   const int c_begin = blockIdx.y * cps, c_end = min(nchunk, c_begin + cps);
   float* outp = a.out + (size_t)blockIdx.y * a.n_host * a.ldo;
@@ -431,13 +433,13 @@ __global__ __launch_bounds__(256, 2) void rp_kchunk_kernel(GemmArgs a) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int col = (wave + 4 * nb) * 32 + l31;
-    const float bv = a.bias ? a.bias[col] : 0.0f;
+    const float bv = (a.bias && first) ? a.bias[col] : 0.0f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = bv;
-        if (EPI == EPI_RESID) {
+        if (EPI == EPI_RESID && first) {
           const int row = min(m0 + mi * 32 + mfma32_row(r, lane), n - 1);
           v += a.resid[(size_t)row * a.ldo + col];
           if (a.cconst) v += a.cconst[(size_t)a.idx[row] * a.ld_cc + col];
@@ -520,6 +522,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   f32x4 s = *(const f32x4*)(slab + i * 4);
   for (int y = 1; y < nsplit; ++y) s += *(const f32x4*)(slab + ((size_t)y * stride4 + i) * 4);
   *(f32x4*)(out + i * 4) = s;
+}
+
+// split-K combine over the LIVE rows only (n read from device memory): out[row][c] = sum_y slab[y][row][c]
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void slab_reduce_rows_kernel(const float* __restrict__ slab, int nsplit, size_t stride,
+                                                               float* __restrict__ out, const int* __restrict__ n_dev, int ldo) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (size_t)*n_dev * ldo) return;
+  f32x4 s = *(const f32x4*)(slab + i);
+  for (int y = 1; y < nsplit; ++y) s += *(const f32x4*)(slab + (size_t)y * stride + i);
+  *(f32x4*)(out + i) = s;
 }
 
 template <int EPI, bool H>
