@@ -380,3 +380,23 @@ def test_edge_cases_against_the_oracle(env, ae_sd, scorer_sd, id_to_word):
                 break
         assert ok, ("edge case diverged from the oracle", s)
         assert int(res.n_iter[s]) == n
+
+
+def test_reverse_order_swaps_the_two_files(env, tmp_path):
+    """--reverse_order (siamese_contrastive.py:256-259) feeds file1 first: with equal learning rates the per-sentence
+    records are the same, in swapped halves."""
+    from style_transfer_amd import main as M
+    common = ["--attack", "--not_nll", "--save_path", GOLD + "/", "--data_path", os.path.join(GOLD, "yelp") + "/",
+              "--ae_checkpoint", "surrogate_ae_yelp.safetensors", "--quiet", "--limit", "3", "--gemm_format", env["fmt"]]
+
+    def blocks(extra, name):
+        log = tmp_path / name
+        assert M.main(common + extra + ["--log_file", str(log)]) == 0
+        bl = open(log).read().split("Sentence Pair.")[1:]
+        return [b.split("\n", 1)[1].rsplit("\n", 1)[0] for b in bl]
+    eq = ["--pos_victim_lr=0.2", "--neg_victim_lr=0.2"]
+    fwd, rev = blocks(eq, "fwd"), blocks(eq + ["--reverse_order"], "rev")
+    assert len(fwd) == 6 and fwd[:3] == rev[3:] and fwd[3:] == rev[:3]
+    # the rate switch is by POSITION in the run (idx < 500, :740), not by file: with only six sentences every one of
+    # them takes --pos_victim_lr, whatever --neg_victim_lr says
+    assert blocks(["--pos_victim_lr=0.2", "--neg_victim_lr=0.9"], "c") == fwd
