@@ -808,8 +808,11 @@ __device__ unsigned long long g_tail_stamps[64];
 #else
 #define TSTAMP(i)
 #endif
+#ifndef RP_TAIL_RING
+#define RP_TAIL_RING 4  /* W fragment ring depth in k-steps (16 steps per pass) */
+#endif
 template <int UNUSED = 0>
-__global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
+__global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_kernel(OFArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* P1 = smem;
   float* P2 = smem + 64 * ST_LDA;
@@ -822,11 +825,12 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
   const int col = wave * 32 + l31;  // this lane's output column (O-projection and FFN2)
   const int nchunk = a.d_ff >> 8;
 
-  // 16 k-steps of one 32-column block: fragments (hi, lo) through a 4-deep register ring
-  f32x4 rh[4], rl[4];
+  // 16 k-steps of one 32-column block: fragments (hi, lo) through a register ring RG steps deep
+  constexpr int RG = RP_TAIL_RING;
+  f32x4 rh[RG], rl[RG];
   auto ring_fill = [&](const f32x4* Wb) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RG; ++j) {
       rh[j] = Wb[(size_t)j * 128];
       rl[j] = Wb[(size_t)j * 128 + 64];
     }
@@ -872,14 +876,16 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail_kernel(OFArgs a) {
   const float* A2 = P2 + l31 * ST_LDA + 4 * half;
   // one 16-step pass: standard orientation (panel rows x W columns) or transposed (W rows x panel rows)
   auto pass = [&](const float* Ab, const f32x4* Wb, f32x16& c0, f32x16& c1, bool transposed) {
-    for (int g0 = 0; g0 < 16; g0 += 4) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+    for (int g0 = 0; g0 < 16; g0 += RG) {
+#pragma unroll
+      for (int j = 0; j < RG; ++j) {
         const int kg = g0 + j;
         const h8 bh = as_h8(rh[j]), bl = as_h8(rl[j]);
-        const int nx = min(kg + 4, 15);
-        rh[j] = Wb[(size_t)nx * 128];
-        rl[j] = Wb[(size_t)nx * 128 + 64];
+        if (kg + RG < 16) {  // static after unrolling: the last RG steps of a pass fetch nothing (ring_fill follows)
+          rh[j] = Wb[(size_t)(kg + RG) * 128];
+          rl[j] = Wb[(size_t)(kg + RG) * 128 + 64];
+        }
         const h8 a0h = as_h8(*(const f32x4*)(Ab + kg * 8)), a0l = as_h8(*(const f32x4*)(Ab + 128 + kg * 8));
         const h8 a1h = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + kg * 8));
         const h8 a1l = as_h8(*(const f32x4*)(Ab + 32 * ST_LDA + 128 + kg * 8));
