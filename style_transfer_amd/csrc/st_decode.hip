@@ -472,7 +472,10 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
     if (screen) {
       // pass 1: one-product logits for every live row; rows with a clear winner are finished
-      ST_TRY(launch_rp_argmax_screen(gg, n_bound, gsplits, st));
+      if (gsplits == 1 && (w->vocab + 127) / 128 <= RS_MAX_BLOCKS)
+        ST_TRY(launch_rp_screen_pipelined(gg, n_bound, st));  // bookkeeping interleaved with the next block's MFMAs
+      else
+        ST_TRY(launch_rp_argmax_screen(gg, n_bound, gsplits, st));
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
                          (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2);

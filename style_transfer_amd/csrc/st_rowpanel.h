@@ -379,6 +379,196 @@ static int launch_rp_argmax_screen(const GemmArgs& a, int n_bound, int splits, h
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
+// ------------------------------------------------------------------------------------------------
+// Screening pass, software-pipelined form (used by st_decode.hip when one workgroup covers all columns of a panel).
+// Ablations of the SCREEN path above (kbench, 229 k rows): without the top-2 bookkeeping the pass takes 38 % less
+// time, without the W loads 17 %, without the LDS reads 6 % - the 4 VALU operations per logit do not overlap with
+// the MFMAs, because a wave's bookkeeping for a block can only start when its last MFMA is done and there are just
+// two waves per SIMD.  Here the bookkeeping of block i-1 is interleaved, in one basic block, with the 32 MFMAs of
+// block i (two accumulator sets), and costs 3 operations per logit: the wave-local block number is written into
+// the low 8 mantissa bits of the logit (key = (v & ~0xff) | i), so the running (best, second) pair is one v_med3
+// and one v_max on keys and the winning column comes out of the key.  Keys are at most 2^-15 |v| below |v|; the
+// reported second value is raised by that bound for both keys, so the caller's margin test stays conservative.
+// Exact ties of keys give a zero gap: such rows are re-done by the 3-product kernel like every ambiguous row.
+// 64-row panel, hi halves only in LDS (33 KiB), 4 waves, no barrier after the prologue.
+// ------------------------------------------------------------------------------------------------
+#define RS_LDA 132  /* dwords per panel row: 256 hi halves + 4 dwords of padding (= 4 mod 64: conflict-free b128) */
+#define RS_LDS ((64 * RS_LDA + 4 * 64 * 4 + 64) * 4)
+#define RS_MAX_BLOCKS 256  /* column blocks per wave that fit the 8 key bits */
+#define RS_PAD_LOGIT (-3.0e38f) /* bias of padding columns: finite, so that its key is not a NaN */
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256, 2) void rp_screen_kernel(GemmArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                  // [64][RS_LDA]
+  float* red = smem + 64 * RS_LDA;   // [4 waves][64 rows][4]
+  float* rownorm = red + 4 * 64 * 4; // [64]
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  {
+    // one wave per row, 16 rows each: global -> registers -> LayerNorm -> hi halves in LDS
+    f32x4 ga = {1, 1, 1, 1}, gb = {0, 0, 0, 0};
+    if (a.ln_a) {
+      ga = *(const f32x4*)(a.ln_a + lane * 4);
+      gb = *(const f32x4*)(a.ln_b + lane * 4);
+    }
+    f32x4 v[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = min(m0 + wave * 16 + rr, n - 1);
+      v[rr] = *(const f32x4*)(a.X + (size_t)(a.xrows ? a.xrows[r] : r) * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = wave * 16 + rr;
+      f32x4 y = v[rr];
+      float nrm = INFINITY;  // no LayerNorm, no norm: every row counts as ambiguous
+      if (a.ln_a) {
+        y = layernorm256(y, ga, gb);
+        nrm = sqrtf(wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w));
+      }
+      if (lane == 0) rownorm[r] = nrm;
+      const float m = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+      if (a.range_flag && !(m <= 65504.0f)) *a.range_flag = 1;
+      h4 hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi[j] = (_Float16)y[j];
+      *(h4*)((_Float16*)(As + r * RS_LDA) + lane * 4) = hi;
+    }
+  }
+  __syncthreads();
+
+  // running (best, second) keys per (row tile, register): start below every finite logit
+  float k1[2][16], k2[2][16];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) k1[mi][r] = k2[mi][r] = -INFINITY;
+  constexpr int SPB = 16, R = 8;
+  const int nblk = (a.N + 31) >> 5;
+  const int cnt = (nblk > wave) ? (nblk - wave + 3) / 4 : 0;  // this wave's blocks: wave, wave + 4, ...
+  const f32x4* Wl = (const f32x4*)a.W + lane;
+  const float* Ab = As + l31 * RS_LDA + 4 * half;
+  auto wbase = [&](int i) -> const f32x4* {  // hi fragment of step g of block i at wbase(i)[g * 128]
+    return Wl + (size_t)(wave + 4 * min(i, cnt - 1)) * SPB * 2 * 64;
+  };
+  auto bias_of = [&](int i) -> float {
+    const int col = ((wave + 4 * i) << 5) + l31;
+    return col < a.N ? (a.bias ? a.bias[col] : 0.0f) : RS_PAD_LOGIT;
+  };
+  auto book = [&](float v, int i, float& b1, float& b2) {  // 3 VALU operations
+    const float key = __int_as_float((__float_as_int(v) & ~0xff) | i);
+    b2 = __builtin_amdgcn_fmed3f(b1, key, b2);
+    b1 = fmaxf(b1, key);
+  };
+  f32x4 ring[R];
+  if (cnt > 0) {
+    const f32x4* W0 = wbase(0);
+#pragma unroll
+    for (int j = 0; j < R; ++j) ring[j] = W0[(size_t)j * 128];
+  }
+  // one block: 16 k-steps into (n0, n1); meanwhile the previous block's accumulators (o0, o1; block number io) are
+  // booked, two logits per k-step.  BOOK = false for the first block.
+  f32x4 an0, an1;  // A fragments of the NEXT k-step (requested one step ahead: LDS latency ~ one step)
+  an0 = *(const f32x4*)(Ab);
+  an1 = *(const f32x4*)(Ab + 32 * RS_LDA);
+  auto block = [&](f32x16& n0, f32x16& n1, int i, const f32x16& o0, const f32x16& o1, int io, bool do_book) {
+    const f32x4* Wb = wbase(i);
+    const f32x4* Wn = wbase(i + 1);
+    const float bv = bias_of(i);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) n0[r] = n1[r] = bv;
+#pragma unroll
+    for (int kg = 0; kg < SPB; ++kg) {
+      const h8 bh = as_h8(ring[kg % R]);
+      const h8 a0h = as_h8(an0), a1h = as_h8(an1);
+      ring[kg % R] = kg + R < SPB ? Wb[(size_t)(kg + R) * 128] : Wn[(size_t)(kg + R - SPB) * 128];
+      an0 = *(const f32x4*)(Ab + ((kg + 1) & (SPB - 1)) * 8);
+      an1 = *(const f32x4*)(Ab + 32 * RS_LDA + ((kg + 1) & (SPB - 1)) * 8);
+      n0 = mfma16h(a0h, bh, n0);
+      n1 = mfma16h(a1h, bh, n1);
+      if (do_book) {
+        book(o0[kg], io, k1[0][kg], k2[0][kg]);
+        book(o1[kg], io, k1[1][kg], k2[1][kg]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the step structure: nothing is hoisted across k-steps (register pressure)
+    }
+  };
+  f32x16 A0, A1, B0, B1;
+  if (cnt > 0) {
+    block(A0, A1, 0, A0, A1, 0, false);
+    int i = 1;
+    for (; i + 1 < cnt; i += 2) {
+      block(B0, B1, i, A0, A1, i - 1, true);
+      block(A0, A1, i + 1, B0, B1, i, true);
+    }
+    if (i < cnt) {  // an even number of blocks: one more into B, then book B
+      block(B0, B1, i, A0, A1, i - 1, true);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        book(B0[r], i, k1[0][r], k2[0][r]);
+        book(B1[r], i, k1[1][r], k2[1][r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        book(A0[r], cnt - 1, k1[0][r], k2[0][r]);
+        book(A1[r], cnt - 1, k1[1][r], k2[1][r]);
+      }
+    }
+  }
+  // keys -> (value, column, second); over the 32 lanes of a half, then over the 4 waves through LDS
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      Top2 t;
+      t.m1 = k1[mi][r];
+      t.i1 = ((wave + 4 * (__float_as_int(k1[mi][r]) & 0xff)) << 5) + l31;
+      t.m2 = k2[mi][r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        Top2 u;
+        u.m1 = __shfl_xor(t.m1, o, 64);
+        u.i1 = __shfl_xor(t.i1, o, 64);
+        u.m2 = __shfl_xor(t.m2, o, 64);
+        t = top2_merge(t, u);
+      }
+      if (l31 == 0) {
+        float* p = red + (wave * 64 + mi * 32 + mfma32_row(r, lane)) * 4;
+        p[0] = t.m1;
+        p[1] = __int_as_float(t.i1);
+        p[2] = t.m2;
+      }
+    }
+  __syncthreads();
+  if (tid < 64 && m0 + tid < n) {
+    Top2 t = {red[tid * 4 + 0], __float_as_int(red[tid * 4 + 1]), red[tid * 4 + 2]};
+    for (int w = 1; w < 4; ++w) {
+      Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
+      t = top2_merge(t, u);
+    }
+    // both keys may sit up to 2^-15 |v| below their logits' magnitudes: report the second value that much higher
+    const float second = t.m2 + 1.01f * (1.0f / 16384.0f) * fmaxf(fabsf(t.m1), fabsf(t.m2));
+    a.partial[(size_t)(m0 + tid)] = make_float4(t.m1, __int_as_float(t.i1), second, rownorm[tid]);
+  }
+}
+// one workgroup per 64-row panel over ALL columns (partials: one per row); needs ceil(N / 128) <= RS_MAX_BLOCKS
+static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, hipStream_t st) {
+  ST_ENSURE_LDS((rp_screen_kernel<0>), RS_LDS);
+  if (n_bound <= 0) return ST_OK;
+  if (a.fmt != ST_GEMM_F16X3 || (a.N + 127) / 128 > RS_MAX_BLOCKS) {
+    st_set_error("rp_screen: needs the f16x3 format and N <= %d (N=%d)", RS_MAX_BLOCKS * 128, a.N);
+    return ST_EINVAL;
+  }
+  hipLaunchKernelGGL((rp_screen_kernel<0>), dim3((n_bound + 63) / 64), dim3(256), RS_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
 // a.fmt selects the operand format the packed W image was built for (ST_GEMM_F32 / ST_GEMM_F16X3)
 // NW is the wave count of the f32 kernel; the f16x3 kernels always run 4 waves (2 workgroups x 4 waves with
 // 256 registers each measured faster than 8-wave workgroups at 128: QKV 199 vs 242 us at 131072 rows)

@@ -370,17 +370,23 @@ def test_large_batch_paths_equal_small_batch(dev, ae, ae_sd):
     assert int(same.sum().item()) >= len(sents) - 1, same.cpu().tolist()
 
 
-def test_screened_argmax_equals_full_product(dev, ae, gold_notnll):
+@pytest.mark.parametrize("copies", [1, 6])
+def test_screened_argmax_equals_full_product(dev, ae, gold_notnll, copies):
     """f16x3 format, >= 2048 live rows: the generator first runs a ONE-product (hi.hi) pass and redoes only the
     rows whose top-2 gap is inside the error bound of that pass with the 3-product kernel.  The emitted ids
-    must equal those of the full product on every row (bit-exact integer work), on distinct latents."""
+    must equal those of the full product on every row (bit-exact integer work), on distinct latents.
+    copies = 1: 6912 rows (column-split screening kernel); copies = 6: 41472 rows (>= 512 panels: the software-
+    pipelined screening kernel with key-packed bookkeeping, rp_screen_kernel)."""
     from style_transfer_amd import ops
     if ae.gemm_format != "f16x3":
         pytest.skip("the screening pass exists only in the f16x3 format")
     rng = np.random.default_rng(5)
     base = gold_notnll["latent"].reshape(-1, 256)                       # 1152 latents of real edit trajectories
-    lat = np.concatenate([base + rng.standard_normal(base.shape).astype(np.float32) * s for s in (0, 0.05, 0.1, 0.2, 0.4, 0.8)])
-    lat = torch.from_numpy(lat.astype(np.float32)).to(dev)              # 6912 distinct rows
+    lat = np.concatenate([base + rng.standard_normal(base.shape).astype(np.float32) * s
+                          for _ in range(copies) for s in (0, 0.05, 0.1, 0.2, 0.4, 0.8)])
+    if copies > 1:
+        lat[:1152 * 6 * (copies - 1):6] += 1e-3                          # the noise-free copies are made distinct too
+    lat = torch.from_numpy(lat.astype(np.float32)).to(dev)              # 6912 x copies distinct rows
     ids_full, _, steps_full = ops.greedy_decode(ae, lat, screen=False)
     ids_scr, _, steps_scr = ops.greedy_decode(ae, lat, screen=True)
     assert steps_full == steps_scr
