@@ -1123,52 +1123,104 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   __syncthreads();
   _Float16* H2 = (_Float16*)P2;
   TSTAMP(4);
-  for (int c = 0; c < nchunk; ++c) {
-    // ---- FFN1, hidden block jb = 8c + wave, transposed: lane = panel row, registers = hidden units ----
-    f32x16 ah0, ah1;
+  // ReLU + f16 split of one accumulator group (4 consecutive hidden units of one panel row) -> hidden chunk in P2
+  auto epi_unit = [&](const f32x16& acc, int g, int rowbase) {
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc[4 * g + q], 0.0f);
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (a.range_flag && !(mx <= 65504.0f)) *a.range_flag = 1;  // hidden unit outside the f16 range (or NaN)
+    h4 hi, lo;
+    split_f16(v, hi, lo);
+    const int jl = wave * 32 + 8 * g + 4 * half;
+    *(h4*)(H2 + (size_t)(rowbase + l31) * (2 * ST_LDA) + jl) = hi;
+    *(h4*)(H2 + (size_t)(rowbase + l31) * (2 * ST_LDA) + 256 + jl) = lo;
+  };
+  // FFN1 pass of the NEXT chunk (transposed, into c0 / c1) with the conversion of the CURRENT chunk's accumulators
+  // (o0 / o1) spread over its k-steps: one basic block, so the VALU / LDS-store work runs in the MFMAs' shadow
+  auto pass_epi = [&](const float* Ab, const f32x4* Wb, f32x16& c0, f32x16& c1, const f32x16& o0, const f32x16& o1) {
+    f32x4 an[4];  // A fragments of the next k-step, requested one step ahead (LDS latency ~ one step)
+    an[0] = *(const f32x4*)(Ab);
+    an[1] = *(const f32x4*)(Ab + 128);
+    an[2] = *(const f32x4*)(Ab + 32 * ST_LDA);
+    an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) {
+      const int j = kg % RG;
+      const h8 bh = as_h8(rh[j]), bl = as_h8(rl[j]);
+      if (kg + RG < 16) {
+        rh[j] = Wb[(size_t)(kg + RG) * 128];
+        rl[j] = Wb[(size_t)(kg + RG) * 128 + 64];
+      }
+      const h8 a0h = as_h8(an[0]), a0l = as_h8(an[1]), a1h = as_h8(an[2]), a1l = as_h8(an[3]);
+      if (kg + 1 < 16) {
+        an[0] = *(const f32x4*)(Ab + (kg + 1) * 8);
+        an[1] = *(const f32x4*)(Ab + 128 + (kg + 1) * 8);
+        an[2] = *(const f32x4*)(Ab + 32 * ST_LDA + (kg + 1) * 8);
+        an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128 + (kg + 1) * 8);
+      }
+      c0 = mfma16h(bh, a0h, c0);
+      c1 = mfma16h(bh, a1h, c1);
+      c0 = mfma16h(bl, a0h, c0);
+      c1 = mfma16h(bl, a1h, c1);
+      c0 = mfma16h(bh, a0l, c0);
+      c1 = mfma16h(bh, a1l, c1);
+      if (kg & 1) {  // 8 conversion units over the 16 steps
+        const int u = kg >> 1;
+        if (u & 1)
+          epi_unit(o1, u >> 1, 32);
+        else
+          epi_unit(o0, u >> 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // nothing is hoisted across k-steps (the 32 A-fragment reads would spill)
+    }
+  };
+  auto ah_init = [&](f32x16& h0, f32x16& h1) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ah0[4 * g + q] = ah1[4 * g + q] = b1n[g][q];
+      for (int q = 0; q < 4; ++q) h0[4 * g + q] = h1[4 * g + q] = b1n[g][q];
     }
-    if (c + 1 < nchunk) b1_fetch(c + 1);  // consumed one chunk later
-    TSTAMP(5 + c * 5);
-    pass(A1, W1b, ah0, ah1, true);
-    TSTAMP(6 + c * 5);
-    // next ring: this wave's W2 fragments for chunk c (k-steps 16c .. 16c+15 of output block `wave`)
+  };
+  // ---- FFN1 of hidden chunk 0 (block jb = 8c + wave, transposed: lane = panel row, registers = hidden units) ----
+  f32x16 ah0, ah1;
+  ah_init(ah0, ah1);
+  if (nchunk > 1) b1_fetch(1);  // consumed one chunk later
+  TSTAMP(5);
+  pass(A1, W1b, ah0, ah1, true);
+  TSTAMP(6);
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    f32x16 an0, an1;
+    if (more) {
+      W1b = (const f32x4*)a.w1 + (size_t)((c + 1) * 8 + wave) * 16 * 128 + lane;
+      ring_fill(W1b);
+      ah_init(an0, an1);
+      if (c + 2 < nchunk) b1_fetch(c + 2);
+    }
+    if (c > 0) __syncthreads();  // every wave is done reading the previous hidden chunk
+    // ---- hidden chunk c -> P2, overlapped with FFN1 of chunk c + 1 ----
+    if (more) {
+      pass_epi(A1, W1b, an0, an1, ah0, ah1);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        epi_unit(ah0, g, 0);
+        epi_unit(ah1, g, 32);
+      }
+    }
+    // this wave's W2 fragments for chunk c (k-steps 16c .. 16c+15 of output block `wave`)
     const f32x4* W2b = (const f32x4*)a.w2 + ((size_t)wave * (a.d_ff >> 4) + c * 16) * 128 + lane;
     ring_fill(W2b);
-    if (c > 0) __syncthreads();  // every wave is done reading the previous hidden chunk
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v0, v1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        v0[q] = fmaxf(ah0[4 * g + q], 0.0f);
-        v1[q] = fmaxf(ah1[4 * g + q], 0.0f);
-      }
-      h4 hi, lo;
-      const int jl = wave * 32 + 8 * g + 4 * half;
-      {
-        const float mx = fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)));
-        if (a.range_flag && !(mx <= 65504.0f)) *a.range_flag = 1;  // hidden unit outside the f16 range (or NaN)
-      }
-      split_f16(v0, hi, lo);
-      *(h4*)(H2 + (size_t)l31 * (2 * ST_LDA) + jl) = hi;
-      *(h4*)(H2 + (size_t)l31 * (2 * ST_LDA) + 256 + jl) = lo;
-      split_f16(v1, hi, lo);
-      *(h4*)(H2 + (size_t)(32 + l31) * (2 * ST_LDA) + jl) = hi;
-      *(h4*)(H2 + (size_t)(32 + l31) * (2 * ST_LDA) + 256 + jl) = lo;
-    }
     TSTAMP(7 + c * 5);
     __syncthreads();  // hidden chunk complete
     TSTAMP(8 + c * 5);
     // ---- FFN2 partial: x += h_c . W2[:, chunk]^T ----
     pass(A2, W2b, ax0, ax1, false);
     TSTAMP(9 + c * 5);
-    if (c + 1 < nchunk) {
-      W1b = (const f32x4*)a.w1 + (size_t)((c + 1) * 8 + wave) * 16 * 128 + lane;
-      ring_fill(W1b);
+    if (more) {
+      ah0 = an0;
+      ah1 = an1;
     }
   }
 #pragma unroll
