@@ -1015,6 +1015,7 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   const int half = lane >> 5, l31 = lane & 31;
   const int col = wave * 32 + l31;  // this lane's output column (O-projection and FFN2)
   const int nchunk = a.d_ff >> 8;
+  TSTAMP(31);
 
   // 16 k-steps of one 32-column block: fragments (hi, lo) through a register ring RG steps deep
   constexpr int RG = RP_TAIL_RING;
@@ -1045,19 +1046,19 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   // ---- O-projection; accumulators start from bias + residual (+ constant) ----
   const f32x4* Wo = (const f32x4*)a.wo + (size_t)wave * 16 * 128 + lane;
   ring_fill(Wo);
-  f32x16 ax0, ax1;
+  // The residual (+ cross-attention constant: a dependent gather through idx) is requested now and joins the
+  // accumulators AFTER the O-projection pass, so only the attention panel's latency stands before the first MFMA.
+  f32x16 ax0, ax1, px0, px1, pc0, pc1;
   {
     const float bv = a.bo[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row0 = min(m0 + mfma32_row(r, lane), n - 1), row1 = min(m0 + 32 + mfma32_row(r, lane), n - 1);
-      float v0 = bv + a.x[(size_t)row0 * 256 + col], v1 = bv + a.x[(size_t)row1 * 256 + col];
-      if (a.cconst) {
-        v0 += a.cconst[(size_t)a.idx[row0] * 256 + col];
-        v1 += a.cconst[(size_t)a.idx[row1] * 256 + col];
-      }
-      ax0[r] = v0;
-      ax1[r] = v1;
+      px0[r] = a.x[(size_t)row0 * 256 + col];
+      px1[r] = a.x[(size_t)row1 * 256 + col];
+      pc0[r] = a.cconst ? a.cconst[(size_t)a.idx[row0] * 256 + col] : 0.0f;
+      pc1[r] = a.cconst ? a.cconst[(size_t)a.idx[row1] * 256 + col] : 0.0f;
+      ax0[r] = ax1[r] = bv;
     }
   }
   TSTAMP(0);
@@ -1106,6 +1107,11 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
     }
   };
   pass(A1, Wo, ax0, ax1, false);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ax0[r] += px0[r] + pc0[r];
+    ax1[r] += px1[r] + pc1[r];
+  }
   TSTAMP(2);
   b1_fetch(0);
   __syncthreads();  // every wave is done reading the attention panel
@@ -1136,13 +1142,14 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   __syncthreads();
   _Float16* H2 = (_Float16*)P2;
   TSTAMP(4);
+  int bad = 0;
   // ReLU + f16 split of one accumulator group (4 consecutive hidden units of one panel row) -> hidden chunk in P2
   auto epi_unit = [&](const f32x16& acc, int g, int rowbase) {
     f32x4 v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc[4 * g + q], 0.0f);
     const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-    if (a.range_flag && !(mx <= 65504.0f)) *a.range_flag = 1;  // hidden unit outside the f16 range (or NaN)
+    bad |= !(mx <= 65504.0f);  // hidden unit outside the f16 range (or NaN); reported once at the end (no branch here)
     h4 hi, lo;
     split_f16(v, hi, lo);
     const int jl = wave * 32 + 8 * g + 4 * half;
@@ -1242,6 +1249,7 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
     if (row0 < n) ST_STORE(&a.x[(size_t)row0 * 256 + col], ax0[r]);
     if (row1 < n) ST_STORE(&a.x[(size_t)row1 * 256 + col], ax1[r]);
   }
+  if (bad && a.range_flag) *a.range_flag = 1;
   TSTAMP(30);
 }
 

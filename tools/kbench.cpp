@@ -158,13 +158,15 @@ int main(int argc, char** argv) {
 #ifdef ST_TAIL_STAMPS
     unsigned long long hs[64];
     CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_tail_stamps), sizeof(hs)));
-    const char* nm[] = {"prologue issued", "barrier0", "O-proj", "barrier1", "x1->LDS + LN + barriers"};
-    for (int i = 1; i <= 4; ++i) printf("  %-28s %8llu\n", nm[i], hs[i] - hs[i - 1]);
+    const char* nm[] = {"entry -> loads issued", "wait + barrier0", "O-proj", "barrier1", "x1->LDS + LN + barriers", "bias init", "FFN1(0)"};
+    printf("  %-32s %8llu\n", nm[0], hs[0] - hs[31]);
+    for (int i = 1; i <= 6; ++i) printf("  %-32s %8llu\n", nm[i], hs[i] - hs[i - 1]);
     for (int c = 0; c < 4; ++c) {
-      printf("  chunk %d: gap %6llu  PA %6llu  hwrite %6llu  barrier %6llu  PB %6llu\n", c, hs[5 + 5 * c] - (c ? hs[4 + 5 * c] : hs[4]),
-             hs[6 + 5 * c] - hs[5 + 5 * c], hs[7 + 5 * c] - hs[6 + 5 * c], hs[8 + 5 * c] - hs[7 + 5 * c], hs[9 + 5 * c] - hs[8 + 5 * c]);
+      const unsigned long long prev = c ? hs[9 + 5 * (c - 1)] : hs[6];
+      printf("  chunk %d: FFN1(c+1) + convert(c) %6llu  barrier %6llu  FFN2 %6llu\n", c, hs[7 + 5 * c] - prev,
+             hs[8 + 5 * c] - hs[7 + 5 * c], hs[9 + 5 * c] - hs[8 + 5 * c]);
     }
-    printf("  epilogue %llu   total %llu (stamp 0 is after the prologue loads were issued)\n", hs[30] - hs[24], hs[30] - hs[0]);
+    printf("  store %llu   total %llu\n", hs[30] - hs[24], hs[30] - hs[31]);
 #endif
   }
   CK(hipDeviceSynchronize());
