@@ -570,6 +570,169 @@ static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, hipStream_
   return ST_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// QKV projections, software-pipelined form (f16x3, one workgroup per 64-row panel over all N columns): the same
+// arithmetic as rp_gemm_kernel<EPI_BIAS / EPI_QKV, 4, true> (LayerNorm'ed split panel in LDS, three products per
+// k-step, bias-initialised accumulators), but with two accumulator sets: while block i runs its 96 MFMAs, the 32
+// output values per lane of block i-1 are stored, two per k-step, inside the same basic block.  In rp_gemm_kernel the
+// stores of a block sit between two blocks' MFMAs and the matrix pipe idles through them (with the stores ablated
+// the QKV kernel was 25 % faster).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_QKV, "rp_lin_kernel: BIAS or QKV");
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;  // [64][ST_LDA]
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int bad = 0;
+  auto store_split = [&](float* row, int c4, f32x4 v) {  // panel_store4<true> without the branch
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    bad |= !(m <= 65504.0f);
+    h4 hi, lo;
+    split_f16(v, hi, lo);
+    _Float16* ph = (_Float16*)row;
+    *(h4*)(ph + c4 * 4) = hi;
+    *(h4*)(ph + 256 + c4 * 4) = lo;
+  };
+  if (a.ln_a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 6, c4 = f & 63;
+      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+    }
+    __syncthreads();
+    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      float* row = As + (wave * 16 + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
+      store_split(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 6, c4 = f & 63;
+      store_split(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4));
+    }
+  }
+  __syncthreads();
+
+  constexpr int SPB = 16, R = 4;
+  const int nblk = (a.N + 31) >> 5;
+  const int cnt = (nblk > wave) ? (nblk - wave + 3) / 4 : 0;  // this wave's blocks: wave, wave + 4, ...
+  const f32x4* Wl = (const f32x4*)a.W + lane;
+  const float* Ab = As + l31 * ST_LDA + 4 * half;
+  auto wbase = [&](int i) -> const f32x4* {  // fragments of step g of block i: hi at [g * 128], lo at [g * 128 + 64]
+    return Wl + (size_t)(wave + 4 * min(i, cnt - 1)) * SPB * 2 * 64;
+  };
+  // this lane's 32 output rows are the same for every block: row offsets once (QKV: also the K/V cache slots)
+  // QKV: the K/V cache slot (job) of each panel row, in the LDS words behind the panel (kept out of the registers)
+  int* slot = (int*)(smem + 64 * ST_LDA);
+  if (EPI == EPI_QKV) {
+    if (tid < 64) slot[tid] = a.idx[min(m0 + tid, n - 1)];
+    __syncthreads();
+  }
+  auto put = [&](float v, int i, int mi, int r) {
+    const int blk = wave + 4 * i;  // wave-uniform: a 32-column block lies entirely in q, k or v
+    const int col = (blk << 5) + l31;
+    const int rl = mi * 32 + mfma32_row(r, lane);
+    if (m0 + rl >= n || col >= a.N) return;
+    if (EPI == EPI_BIAS) {
+      ST_STORE(&a.out[(size_t)(m0 + rl) * a.ldo + col], v);
+    } else if (blk < 8) {
+      ST_STORE(&a.q[(size_t)(m0 + rl) * 256 + col], v);
+    } else {
+      float* base = (blk < 16) ? a.kbase : a.vbase;
+      ST_STORE(&base[(long)slot[rl] * a.kv_stride + (col & 255)], v);
+    }
+  };
+  f32x4 rh[R], rl[R];
+  if (cnt > 0) {
+    const f32x4* W0 = wbase(0);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      rh[j] = W0[(size_t)j * 128];
+      rl[j] = W0[(size_t)j * 128 + 64];
+    }
+  }
+  f32x4 an[4];
+  an[0] = *(const f32x4*)(Ab);
+  an[1] = *(const f32x4*)(Ab + 128);
+  an[2] = *(const f32x4*)(Ab + 32 * ST_LDA);
+  an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
+  auto block = [&](f32x16& n0, f32x16& n1, int i, const f32x16& o0, const f32x16& o1, int io, bool do_put) {
+    const f32x4* Wb = wbase(i);
+    const f32x4* Wn = wbase(i + 1);
+    const int col = ((wave + 4 * i) << 5) + l31;
+    const float bv = (a.bias && col < a.N) ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) n0[r] = n1[r] = bv;
+#pragma unroll
+    for (int kg = 0; kg < SPB; ++kg) {
+      const h8 bh = as_h8(rh[kg % R]), bl = as_h8(rl[kg % R]);
+      const f32x4* Wx = kg + R < SPB ? Wb + (size_t)(kg + R) * 128 : Wn + (size_t)(kg + R - SPB) * 128;
+      rh[kg % R] = Wx[0];
+      rl[kg % R] = Wx[64];
+      const h8 a0h = as_h8(an[0]), a0l = as_h8(an[1]), a1h = as_h8(an[2]), a1l = as_h8(an[3]);
+      const int kn = (kg + 1) & (SPB - 1);
+      an[0] = *(const f32x4*)(Ab + kn * 8);
+      an[1] = *(const f32x4*)(Ab + 128 + kn * 8);
+      an[2] = *(const f32x4*)(Ab + 32 * ST_LDA + kn * 8);
+      an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128 + kn * 8);
+      n0 = mfma16h(a0h, bh, n0);
+      n1 = mfma16h(a1h, bh, n1);
+      n0 = mfma16h(a0h, bl, n0);
+      n1 = mfma16h(a1h, bl, n1);
+      n0 = mfma16h(a0l, bh, n0);
+      n1 = mfma16h(a1l, bh, n1);
+      if (do_put) {
+        put(o0[kg], io, 0, kg);
+        put(o1[kg], io, 1, kg);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  f32x16 A0, A1, B0, B1;
+  if (cnt > 0) {
+    block(A0, A1, 0, A0, A1, 0, false);
+    int i = 1;
+    for (; i + 1 < cnt; i += 2) {
+      block(B0, B1, i, A0, A1, i - 1, true);
+      block(A0, A1, i + 1, B0, B1, i, true);
+    }
+    if (i < cnt) {
+      block(B0, B1, i, A0, A1, i - 1, true);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        put(B0[r], i, 0, r);
+        put(B1[r], i, 1, r);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        put(A0[r], cnt - 1, 0, r);
+        put(A1[r], cnt - 1, 1, r);
+      }
+    }
+  }
+  if (bad && a.range_flag) *a.range_flag = 1;
+}
+template <int EPI>
+static int launch_rp_lin_pipelined(const GemmArgs& a, int n_bound, hipStream_t st) {
+  ST_ENSURE_LDS((rp_lin_kernel<EPI>), RP_LDS);
+  if (n_bound <= 0) return ST_OK;
+  hipLaunchKernelGGL((rp_lin_kernel<EPI>), dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
 // a.fmt selects the operand format the packed W image was built for (ST_GEMM_F32 / ST_GEMM_F16X3)
 // NW is the wave count of the f32 kernel; the f16x3 kernels always run 4 waves (2 workgroups x 4 waves with
 // 256 registers each measured faster than 8-wave workgroups at 128: QKV 199 vs 242 us at 131072 rows)
