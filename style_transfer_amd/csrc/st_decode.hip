@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const float4* __restrict__ 
     }
     r = rows ? rows[i] : i;
   }
-  const bool amb = valid && margin_c >= 0.0f && !(t.m1 - t.m2 > margin_c * norm + 1e-4f);
+  // rp_screen_kernel reports keys: logits with their low 8 mantissa bits replaced, i.e. each within 2^-15 of its
+  // magnitude; the third term covers both values of any pair, whichever split they came from
+  const float key_err = (1.01f / 16384.0f) * fmaxf(fabsf(t.m1), fabsf(t.m2));
+  const bool amb = valid && margin_c >= 0.0f && !(t.m1 - t.m2 > margin_c * norm + 1e-4f + key_err);
   if (margin_c >= 0.0f) {  // uniform
     const int slot = wave_append(n_amb, amb);
     if (amb) amb_idx[slot] = r;
@@ -476,8 +479,8 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
     if (screen) {
       // pass 1: one-product logits for every live row; rows with a clear winner are finished
-      if (gsplits == 1 && (w->vocab + 127) / 128 <= RS_MAX_BLOCKS)
-        ST_TRY(launch_rp_screen_pipelined(gg, n_bound, st));  // bookkeeping interleaved with the next block's MFMAs
+      if ((w->vocab + 127) / 128 <= RS_MAX_BLOCKS)
+        ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
       else
         ST_TRY(launch_rp_argmax_screen(gg, n_bound, gsplits, st));
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx, n_dev,

@@ -381,7 +381,7 @@ static int launch_rp_argmax_screen(const GemmArgs& a, int n_bound, int splits, h
   return ST_OK;
 }
 // ------------------------------------------------------------------------------------------------
-// Screening pass, software-pipelined form (used by st_decode.hip when one workgroup covers all columns of a panel).
+// Screening pass, software-pipelined form (the one st_decode.hip uses; grid = panels x column splits).
 // Ablations of the SCREEN path above (kbench, 229 k rows): without the top-2 bookkeeping the pass takes 38 % less
 // time, without the W loads 17 %, without the LDS reads 6 % - the 4 VALU operations per logit do not overlap with
 // the MFMAs, because a wave's bookkeeping for a block can only start when its last MFMA is done and there are just
@@ -389,7 +389,7 @@ static int launch_rp_argmax_screen(const GemmArgs& a, int n_bound, int splits, h
 // block i (two accumulator sets), and costs 3 operations per logit: the wave-local block number is written into
 // the low 8 mantissa bits of the logit (key = (v & ~0xff) | i), so the running (best, second) pair is one v_med3
 // and one v_max on keys and the winning column comes out of the key.  Keys are at most 2^-15 |v| below |v|; the
-// reported second value is raised by that bound for both keys, so the caller's margin test stays conservative.
+// caller's margin test (finish_kernel) carries a term for that bound.
 // Exact ties of keys give a zero gap: such rows are re-done by the 3-product kernel like every ambiguous row.
 // 64-row panel, hi halves only in LDS (33 KiB), 4 waves, no barrier after the prologue.
 // ------------------------------------------------------------------------------------------------
@@ -450,14 +450,17 @@ __global__ __launch_bounds__(256, 2) void rp_screen_kernel(GemmArgs a) {
     for (int r = 0; r < 16; ++r) k1[mi][r] = k2[mi][r] = -INFINITY;
   constexpr int SPB = 16, R = 8;
   const int nblk = (a.N + 31) >> 5;
-  const int cnt = (nblk > wave) ? (nblk - wave + 3) / 4 : 0;  // this wave's blocks: wave, wave + 4, ...
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;  // column split blockIdx.y covers blocks [b0, b1)
+  const int b0 = blockIdx.y * per;
+  const int b1 = min(nblk, b0 + per);
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) / 4 : 0;  // this wave's blocks: b0 + wave, b0 + wave + 4, ...
   const f32x4* Wl = (const f32x4*)a.W + lane;
   const float* Ab = As + l31 * RS_LDA + 4 * half;
   auto wbase = [&](int i) -> const f32x4* {  // hi fragment of step g of block i at wbase(i)[g * 128]
-    return Wl + (size_t)(wave + 4 * min(i, cnt - 1)) * SPB * 2 * 64;
+    return Wl + (size_t)(b0 + wave + 4 * min(i, cnt - 1)) * SPB * 2 * 64;
   };
   auto bias_of = [&](int i) -> float {
-    const int col = ((wave + 4 * i) << 5) + l31;
+    const int col = ((b0 + wave + 4 * i) << 5) + l31;
     return col < a.N ? (a.bias ? a.bias[col] : 0.0f) : RS_PAD_LOGIT;
   };
   auto book = [&](float v, int i, float& b1, float& b2) {  // 3 VALU operations
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void rp_screen_kernel(GemmArgs a) {
     for (int r = 0; r < 16; ++r) {
       Top2 t;
       t.m1 = k1[mi][r];
-      t.i1 = ((wave + 4 * (__float_as_int(k1[mi][r]) & 0xff)) << 5) + l31;
+      t.i1 = ((b0 + wave + 4 * (__float_as_int(k1[mi][r]) & 0xff)) << 5) + l31;
       t.m2 = k2[mi][r];
 #pragma unroll
       for (int o = 1; o < 32; o <<= 1) {
@@ -552,20 +555,19 @@ __global__ __launch_bounds__(256, 2) void rp_screen_kernel(GemmArgs a) {
       Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
       t = top2_merge(t, u);
     }
-    // both keys may sit up to 2^-15 |v| below their logits' magnitudes: report the second value that much higher
-    const float second = t.m2 + 1.01f * (1.0f / 16384.0f) * fmaxf(fabsf(t.m1), fabsf(t.m2));
-    a.partial[(size_t)(m0 + tid)] = make_float4(t.m1, __int_as_float(t.i1), second, rownorm[tid]);
+    // keys sit up to 2^-15 |v| off their logits: finish_kernel's margin has a term for that
+    a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, rownorm[tid]);
   }
 }
-// one workgroup per 64-row panel over ALL columns (partials: one per row); needs ceil(N / 128) <= RS_MAX_BLOCKS
-static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, hipStream_t st) {
+// grid (panels, column splits); needs ceil(N / 128) <= RS_MAX_BLOCKS (the block number must fit the 8 key bits)
+static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   ST_ENSURE_LDS((rp_screen_kernel<0>), RS_LDS);
   if (n_bound <= 0) return ST_OK;
   if (a.fmt != ST_GEMM_F16X3 || (a.N + 127) / 128 > RS_MAX_BLOCKS) {
     st_set_error("rp_screen: needs the f16x3 format and N <= %d (N=%d)", RS_MAX_BLOCKS * 128, a.N);
     return ST_EINVAL;
   }
-  hipLaunchKernelGGL((rp_screen_kernel<0>), dim3((n_bound + 63) / 64), dim3(256), RS_LDS, st, a);
+  hipLaunchKernelGGL((rp_screen_kernel<0>), dim3((n_bound + 63) / 64, splits), dim3(256), RS_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
     const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(n, V, 16);
     t = timeit([&] { launch_rp_argmax_screen(g, n, sp, st); });
     printf("gen screen n=%d splits=%d: %8.1f us %6.1f TF (one product)\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
-    t = timeit([&] { launch_rp_screen_pipelined(g, n, st); });
+    t = timeit([&] { launch_rp_screen_pipelined(g, n, sp, st); });
     printf("gen screen, pipelined bookkeeping n=%d: %8.1f us %6.1f TF (one product)\n", n, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
   }
   if (want('f')) {  // FFN1 (rp RELU)
