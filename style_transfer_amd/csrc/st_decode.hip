@@ -411,8 +411,8 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
       const int qsplits = rp_splits(n_bound, 768, n_bound <= 2048 ? 8 : 3, rp_nw(w->gemm_format, 8));
-      if (w->gemm_format == ST_GEMM_F16X3 && qsplits == 1)
-        ST_TRY(launch_rp_lin_pipelined<EPI_QKV>(g, n_bound, st));  // stores of block i-1 inside the MFMAs of block i
+      if (w->gemm_format == ST_GEMM_F16X3)
+        ST_TRY(launch_rp_lin_pipelined<EPI_QKV>(g, n_bound, qsplits, st));  // stores of block i-1 inside the MFMAs of block i
       else
         ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, qsplits, st)));
       if (pos < 16)

@@ -196,8 +196,8 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
     g.out = qkv; g.ldo = 768;
     const int qsplits = rp_splits(R, 768, 3, rp_nw(w->gemm_format, 8));
-    if (w->gemm_format == ST_GEMM_F16X3 && qsplits == 1)
-      ST_TRY(launch_rp_lin_pipelined<EPI_BIAS>(g, R, st));
+    if (w->gemm_format == ST_GEMM_F16X3)
+      ST_TRY(launch_rp_lin_pipelined<EPI_BIAS>(g, R, qsplits, st));
     else
       ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, qsplits, st)));
     hipLaunchKernelGGL(enc_attn16_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);

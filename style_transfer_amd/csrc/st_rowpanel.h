@@ -573,7 +573,7 @@ static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, int splits
 }
 
 // ------------------------------------------------------------------------------------------------
-// QKV projections, software-pipelined form (f16x3, one workgroup per 64-row panel over all N columns): the same
+// QKV projections, software-pipelined form (f16x3; grid = 64-row panels x column splits): the same
 // arithmetic as rp_gemm_kernel<EPI_BIAS / EPI_QKV, 4, true> (LayerNorm'ed split panel in LDS, three products per
 // k-step, bias-initialised accumulators), but with two accumulator sets: while block i runs its 96 MFMAs, the 32
 // output values per lane of block i-1 are stored, two per k-step, inside the same basic block.  In rp_gemm_kernel the
@@ -628,11 +628,14 @@ __global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
 
   constexpr int SPB = 16, R = 4;
   const int nblk = (a.N + 31) >> 5;
-  const int cnt = (nblk > wave) ? (nblk - wave + 3) / 4 : 0;  // this wave's blocks: wave, wave + 4, ...
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;  // column split blockIdx.y covers blocks [b0, b1)
+  const int b0 = blockIdx.y * per;
+  const int b1 = min(nblk, b0 + per);
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) / 4 : 0;  // this wave's blocks: b0 + wave, b0 + wave + 4, ...
   const f32x4* Wl = (const f32x4*)a.W + lane;
   const float* Ab = As + l31 * ST_LDA + 4 * half;
   auto wbase = [&](int i) -> const f32x4* {  // fragments of step g of block i: hi at [g * 128], lo at [g * 128 + 64]
-    return Wl + (size_t)(wave + 4 * min(i, cnt - 1)) * SPB * 2 * 64;
+    return Wl + (size_t)(b0 + wave + 4 * min(i, cnt - 1)) * SPB * 2 * 64;
   };
   // this lane's 32 output rows are the same for every block: row offsets once (QKV: also the K/V cache slots)
   // QKV: the K/V cache slot (job) of each panel row, in the LDS words behind the panel (kept out of the registers)
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
     __syncthreads();
   }
   auto put = [&](float v, int i, int mi, int r) {
-    const int blk = wave + 4 * i;  // wave-uniform: a 32-column block lies entirely in q, k or v
+    const int blk = b0 + wave + 4 * i;  // wave-uniform: a 32-column block lies entirely in q, k or v
     const int col = (blk << 5) + l31;
     const int rl = mi * 32 + mfma32_row(r, lane);
     if (m0 + rl >= n || col >= a.N) return;
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
   auto block = [&](f32x16& n0, f32x16& n1, int i, const f32x16& o0, const f32x16& o1, int io, bool do_put) {
     const f32x4* Wb = wbase(i);
     const f32x4* Wn = wbase(i + 1);
-    const int col = ((wave + 4 * i) << 5) + l31;
+    const int col = ((b0 + wave + 4 * i) << 5) + l31;
     const float bv = (a.bias && col < a.N) ? a.bias[col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) n0[r] = n1[r] = bv;
@@ -727,10 +730,10 @@ __global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
   if (bad && a.range_flag) *a.range_flag = 1;
 }
 template <int EPI>
-static int launch_rp_lin_pipelined(const GemmArgs& a, int n_bound, hipStream_t st) {
+static int launch_rp_lin_pipelined(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   ST_ENSURE_LDS((rp_lin_kernel<EPI>), RP_LDS);
   if (n_bound <= 0) return ST_OK;
-  hipLaunchKernelGGL((rp_lin_kernel<EPI>), dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
+  hipLaunchKernelGGL((rp_lin_kernel<EPI>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

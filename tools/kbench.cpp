@@ -125,7 +125,7 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_rp<EPI_BIAS, 8>(g, n, sp, st); });
     printf("qkv NW=8   n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
     if (g_fmt == ST_GEMM_F16X3) {
-      t = timeit([&] { launch_rp_lin_pipelined<EPI_BIAS>(g, n, st); });
+      t = timeit([&] { launch_rp_lin_pipelined<EPI_BIAS>(g, n, sp, st); });
       printf("qkv pipelined stores n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
     }
   }
