@@ -68,14 +68,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32768, help="sentences per GPU per step (KV cache: 241 KB per decode job, 12 jobs per sentence in the first round)")
+    ap.add_argument("--batch", type=int, default=32768, help="sentences per GPU per step (KV cache: 241 KB per decode job, 13 jobs per sentence in the first round)")
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
     ap.add_argument("--tokens", default="zipf", choices=["zipf", "uniform", "real"],
                     help="synthetic token ids: unigram (Zipfian) from word_to_id.txt counts, uniform in [4,V), or the "
                          "1000 real yelp test sentences tiled to the batch size")
     ap.add_argument("--fixed-steps", action="store_true", help="no early exit at EOS: always 59 decode steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--iters-per-decode", default="11,7", help="edit iterations decoded per round: an int or a schedule like 9,5,4")
+    ap.add_argument("--iters-per-decode", default="12,6", help="edit iterations decoded per round: an int or a schedule like 9,5,4")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--distinct-batches", action="store_true",
                     help="a different synthetic batch for every warm-up and timed step (BASELINE config 4: --steps 31 = 1 M distinct "
@@ -200,7 +200,7 @@ def main():
             # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
             alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
             default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 32768 and not a.fixed_steps
-                           and a.iters_per_decode == "11,7")
+                           and a.iters_per_decode == "12,6")
             if default_cfg and os.path.exists(tfile):
                 traffic = json.load(open(tfile))["bytes_per_launch"]
                 traffic_src = "profiles/r01_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"

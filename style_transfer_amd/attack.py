@@ -54,7 +54,7 @@ class AttackConfig:
     # schedule of round sizes, e.g. (9, 3, 3, 3): later rounds are shorter because sentences that reach their 7th
     # change inside a round have the rest of that round's decodes discarded (44 % of yelp-shaped sentences run all
     # 18 iterations, the others stop anywhere from iteration 7 on)
-    iters_per_decode: object = (11, 7)
+    iters_per_decode: object = (12, 6)
     defer_stragglers: bool = True  # see run_prepared: sentences whose decodes do not end are finished in an extra round
     count_units: bool = False
 
