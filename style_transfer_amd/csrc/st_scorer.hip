@@ -28,16 +28,34 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float*
                                             uint32_t* __restrict__ bits, int bits_ld) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  for (int c = wave; c < N / 32; c += SC_NW) {
+  // W fragments (fragment-packed by st_pack_weight, 1 KiB per wave load) run through an 8-deep register ring that
+  // continues into the wave's next 32-column chunk, so only the first chunk of a layer waits for L2
+  constexpr int KS = K / 8, RW = 8;
+  static_assert(KS % RW == 0, "K must be a multiple of 64");
+  const int nch = (N / 32 > wave) ? (N / 32 - wave + SC_NW - 1) / SC_NW : 0;
+  auto wfrag = [&](int ci, int kg) -> f32x4 {
+    const int c = wave + SC_NW * min(ci, nch - 1);
+    return *(const f32x4*)(W + ((size_t)c * KS + kg) * 256 + (size_t)lane * 4);
+  };
+  f32x4 ring[RW];
+  if (nch > 0) {
+#pragma unroll
+    for (int j = 0; j < RW; ++j) ring[j] = wfrag(0, j);
+  }
+  for (int ci = 0; ci < nch; ++ci) {
+    const int c = wave + SC_NW * ci;
     f32x16 acc = {0};
     const float* xr = Xs + l31 * SC_LD + 4 * half;
-    const float* wr = W + ((size_t)c * (K / 8)) * 256 + (size_t)lane * 4;  // fragment-packed (st_pack_weight)
-#pragma unroll 8
-    for (int kg = 0; kg < K / 8; ++kg) {
-      const f32x4 a = *(const f32x4*)(xr + kg * 8);
-      const f32x4 b = *(const f32x4*)(wr + (size_t)kg * 256);
+    for (int kg0 = 0; kg0 < KS; kg0 += RW) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
+      for (int j = 0; j < RW; ++j) {
+        const int kg = kg0 + j;
+        const f32x4 b = ring[j];
+        ring[j] = kg + RW < KS ? wfrag(ci, kg + RW) : wfrag(ci + 1, kg + RW - KS);
+        const f32x4 a = *(const f32x4*)(xr + kg * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
+      }
     }
     const int col = c * 32 + l31;
     const float bv = FWD ? bias[col] : 0.0f;
