@@ -197,23 +197,36 @@ __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restric
 //   column is certainly the exact argmax when it leads the runner-up by more than 2E; otherwise the row
 //   is appended to amb_idx and decided by the 3-product kernel.
 // ------------------------------------------------------------------------------------------------
-// slot in an append-only list for every lane with pred set: ONE atomic per wave (all 64 lanes must call)
-__device__ __forceinline__ int wave_append(int* counter, bool pred) {
+// slot in an append-only list for every thread with pred set: ONE atomic per 1024-thread block (all threads must
+// call).  With one atomic per wave the ~7 k same-address atomics of a 230 k-row step took most of the kernel's 29 us.
+#define FIN_THREADS 1024
+__device__ __forceinline__ int block_append(int* counter, bool pred, int* lds /* [FIN_THREADS / 64 + 1] */) {
   const unsigned long long mask = __ballot(pred);
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0 && mask) base = atomicAdd(counter, __popcll(mask));
-  base = __shfl(base, 0, 64);
-  return base + __popcll(mask & ((1ull << lane) - 1ull));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();  // lds may still be read from a previous call
+  if (lane == 0) lds[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < FIN_THREADS / 64; ++w) {
+      const int c = lds[w];
+      lds[w] = tot;
+      tot += c;
+    }
+    lds[FIN_THREADS / 64] = tot ? atomicAdd(counter, tot) : 0;
+  }
+  __syncthreads();
+  return lds[FIN_THREADS / 64] + lds[wave] + __popcll(mask & ((1ull << lane) - 1ull));
 }
 
-__global__ __launch_bounds__(256) void finish_kernel(const float4* __restrict__ partial, int nsplit,
+__global__ __launch_bounds__(FIN_THREADS) void finish_kernel(const float4* __restrict__ partial, int nsplit,
                                                      const int* __restrict__ idx, const int* __restrict__ n_dev,
                                                      int32_t* __restrict__ ys, float* __restrict__ gap, int T, int pos,
                                                      int eos, int pad, int early, int last, int* __restrict__ idx_next,
                                                      int* __restrict__ n_next, const int* __restrict__ rows,
                                                      float margin_c, int* __restrict__ amb_idx, int* __restrict__ n_amb) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ int app[FIN_THREADS / 64 + 1];
+  const int i = blockIdx.x * FIN_THREADS + threadIdx.x;
   const bool valid = i < *n_dev;
   Top2 t = {0.0f, 0, 0.0f};
   float norm = 0.0f;
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float4* __restrict__ 
   const float key_err = (1.01f / 16384.0f) * fmaxf(fabsf(t.m1), fabsf(t.m2));
   const bool amb = valid && margin_c >= 0.0f && !(t.m1 - t.m2 > margin_c * norm + 1e-4f + key_err);
   if (margin_c >= 0.0f) {  // uniform
-    const int slot = wave_append(n_amb, amb);
+    const int slot = block_append(n_amb, amb, app);
     if (amb) amb_idx[slot] = r;
   }
   const bool emit = valid && !amb;
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float4* __restrict__ 
     if (gap) gap[(size_t)s * T + pos] = t.m1 - t.m2;
   }
   const bool live = emit && !(last || (early && (t.i1 == eos || t.i1 == pad)));
-  const int slot = wave_append(n_next, live);
+  const int slot = block_append(n_next, live, app);
   if (live) idx_next[slot] = s;
 }
 
@@ -483,7 +496,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
       else
         ST_TRY(launch_rp_argmax_screen(gg, n_bound, gsplits, st));
-      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx, n_dev,
+      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
                          (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2);
       ST_LAUNCH_CHECK();
@@ -492,13 +505,13 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       gg.xrows = ws.amb; gg.n_dev = ws.cnt + 2;
       const int rsplits = rp_splits((n_bound + 15) / 16, w->vocab, ST_GEN_SPLITS);
       ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, rsplits, st));
-      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, rsplits, idx, ws.cnt + 2,
+      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, rsplits, idx, ws.cnt + 2,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
                          (const int*)ws.amb, -1.0f, (int*)nullptr, (int*)nullptr);
       ST_LAUNCH_CHECK();
     } else {
       ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, gsplits, st));
-      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + 255) / 256), dim3(256), 0, st, ws.partial, gsplits, idx, n_dev,
+      hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, top2gap, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
                          (const int*)nullptr, -1.0f, (int*)nullptr, (int*)nullptr);
       ST_LAUNCH_CHECK();
