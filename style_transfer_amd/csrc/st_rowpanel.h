@@ -1292,7 +1292,9 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   }
   const f32x4* W1b = (const f32x4*)a.w1 + (size_t)wave * 16 * 128 + lane;  // hidden block (chunk*8 + wave)
   ring_fill(W1b);
+  TSTAMP(32);
   __syncthreads();
+  TSTAMP(33);
   {
 #pragma unroll 4
     for (int rr = 0; rr < 8; ++rr) {
@@ -1307,6 +1309,7 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
       ax1[r] += b2v;
     }
   }
+  TSTAMP(34);
   __syncthreads();
   _Float16* H2 = (_Float16*)P2;
   TSTAMP(4);

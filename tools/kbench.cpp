@@ -165,6 +165,7 @@ int main(int argc, char** argv) {
     const char* nm[] = {"entry -> loads issued", "wait + barrier0", "O-proj", "barrier1", "x1->LDS + LN + barriers", "bias init", "FFN1(0)"};
     printf("  %-32s %8llu\n", nm[0], hs[0] - hs[31]);
     for (int i = 1; i <= 6; ++i) printf("  %-32s %8llu\n", nm[i], hs[i] - hs[i - 1]);
+    printf("    of which: x1 -> LDS %llu, barrier %llu, LayerNorm %llu, barrier %llu\n", hs[32] - hs[3], hs[33] - hs[32], hs[34] - hs[33], hs[4] - hs[34]);
     for (int c = 0; c < 4; ++c) {
       const unsigned long long prev = c ? hs[9 + 5 * (c - 1)] : hs[6];
       printf("  chunk %d: FFN1(c+1) + convert(c) %6llu  barrier %6llu  FFN2 %6llu\n", c, hs[7 + 5 * c] - prev,
