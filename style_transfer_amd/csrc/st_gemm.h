@@ -93,6 +93,16 @@ __device__ __forceinline__ f32x4 layernorm256(f32x4 v, f32x4 ga, f32x4 gb) {
   const float den = sqrtf(ss * (1.0f / 255.0f)) + 1e-6f;
   return (ga * d) / den + gb;
 }
+// The same with one division per row instead of four (f16x3 kernels: the result is split into f16 hi + lo right
+// away, so the <= 1 ulp difference to the form above is below the format's own 2^-22)
+__device__ __forceinline__ f32x4 layernorm256r(f32x4 v, f32x4 ga, f32x4 gb) {
+  float s = wave_sum(v.x + v.y + v.z + v.w);
+  const float mean = s * (1.0f / 256.0f);
+  f32x4 d = v - mean;
+  float ss = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+  const float inv = 1.0f / (sqrtf(ss * (1.0f / 255.0f)) + 1e-6f);
+  return (ga * d) * inv + gb;
+}
 
 // ------------------------------------------------------------------------------------------------
 // kloop_gemm: 128x128 tile, BK = 32, 256 threads (2x2 waves, each 64x64 = 2x2 MFMA tiles).

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
 #pragma unroll 4
     for (int rr = 0; rr < 64 / NW; ++rr) {
       float* row = As + (wave * (64 / NW) + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
-      const f32x4 y = layernorm256(*(f32x4*)(row + lane * 4), ga, gb);
+      const f32x4 y = H ? layernorm256r(*(f32x4*)(row + lane * 4), ga, gb) : layernorm256(*(f32x4*)(row + lane * 4), ga, gb);
       if (SCREEN) {
         const float ss = wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
         if (lane == 0) rownorm[wave * (64 / NW) + rr] = sqrtf(ss);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void rp_screen_kernel(GemmArgs a) {
       f32x4 y = v[rr];
       float nrm = INFINITY;  // no LayerNorm, no norm: every row counts as ambiguous
       if (a.ln_a) {
-        y = layernorm256(y, ga, gb);
+        y = layernorm256r(y, ga, gb);
         nrm = sqrtf(wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w));
       }
       if (lane == 0) rownorm[r] = nrm;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
 #pragma unroll 4
     for (int rr = 0; rr < 16; ++rr) {
       float* row = As + (wave * 16 + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
-      store_split(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb));
+      store_split(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb));
     }
   } else {
 #pragma unroll
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
 #pragma unroll 4
     for (int rr = 0; rr < 8; ++rr) {
       float* row = P1 + (wave * 8 + rr) * ST_LDA;
-      panel_store4<true>(row, lane, layernorm256(*(f32x4*)(row + lane * 4), ga, gb), a.range_flag);
+      panel_store4<true>(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), a.range_flag);
     }
   }
   {
