@@ -487,15 +487,13 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     const long room = ((long)B * ST_GEN_SPLITS + 64L * ST_GEN_SPLITS_SMALL) / n_bound;
     const int gsplits = rp_splits(n_bound, w->vocab, (int)(room < ST_GEN_SPLITS_SMALL ? (room < ST_GEN_SPLITS ? ST_GEN_SPLITS : room) : ST_GEN_SPLITS_SMALL));
     const int last = pos == T - 1 ? 1 : 0;
-    const bool screen = screen_ok && n_bound >= ST_SCREEN_MIN_ROWS;
+    // (a vocabulary beyond 32768 would not fit the block number into the screening kernel's 8 key bits: no screening)
+    const bool screen = screen_ok && n_bound >= ST_SCREEN_MIN_ROWS && (w->vocab + 127) / 128 <= RS_MAX_BLOCKS;
     ProfPair pp;
     if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
     if (screen) {
       // pass 1: one-product logits for every live row; rows with a clear winner are finished
-      if ((w->vocab + 127) / 128 <= RS_MAX_BLOCKS)
-        ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
-      else
-        ST_TRY(launch_rp_argmax_screen(gg, n_bound, gsplits, st));
+      ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
                          (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2);

@@ -50,15 +50,11 @@ __device__ __forceinline__ void panel_store4(float* row, int c4, f32x4 v, int* f
   }
 }
 
-// SCREEN (EPI_ARGMAX, H only): the cheap first pass of the screened argmax (st_decode.hip): ONE product per
-// term (hi.hi, no lo fragments are loaded) and the row's 2-norm in partial.w, from which the caller bounds
-// the error of these logits; rows whose top-2 gap is inside the bound are redone by the 3-product kernel.
-template <int EPI, int NW = 4, bool H = false, bool SCREEN = false>
+template <int EPI, int NW = 4, bool H = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;                  // [64][ST_LDA]
   float* red = smem + 64 * ST_LDA;   // [NW waves][64 rows][4]
-  float* rownorm = red + 4 * 64 * 4; // [64] (SCREEN; NW == 4 leaves the upper half of `red` free)
   const int n = a.n_dev ? *a.n_dev : a.n_host;
   const int m0 = blockIdx.x * 64;
   if (m0 >= n) return;
@@ -82,10 +78,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
     for (int rr = 0; rr < 64 / NW; ++rr) {
       float* row = As + (wave * (64 / NW) + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
       const f32x4 y = H ? layernorm256r(*(f32x4*)(row + lane * 4), ga, gb) : layernorm256(*(f32x4*)(row + lane * 4), ga, gb);
-      if (SCREEN) {
-        const float ss = wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
-        if (lane == 0) rownorm[wave * (64 / NW) + rr] = sqrtf(ss);
-      }
       panel_store4<H>(row, lane, y, a.range_flag);
     }
   } else {
@@ -95,7 +87,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
       const int r = f >> 6, c4 = f & 63;
       panel_store4<H>(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)xrow(min(m0 + r, n - 1)) * 256 + c4 * 4), a.range_flag);
     }
-    if (SCREEN && tid < 64) rownorm[tid] = INFINITY;  // no norm available: every row counts as ambiguous
   }
   __syncthreads();
 
@@ -134,12 +125,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
     const int blk = b0 + wave + NW * (g / SPB);
     return H ? Wl[(((size_t)blk * SPB + (g & (SPB - 1))) * 2 + p) * 64] : Wl[((size_t)blk * SPB + (g & (SPB - 1))) * 64];
   };
-  f32x4 ring[R], ringl[(H && !SCREEN) ? R : 1];
+  f32x4 ring[R], ringl[H ? R : 1];
   if (total > 0) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       ring[j] = wload(j, 0);
-      if (H && !SCREEN) ringl[j] = wload(j, 1);
+      if (H) ringl[j] = wload(j, 1);
     }
   }
   const float* Ab = As + l31 * ST_LDA + 4 * half;
@@ -158,10 +149,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   if (H) {
     an[0] = *(const f32x4*)(Ab);
     an[2] = *(const f32x4*)(Ab + 32 * ST_LDA);
-    if (!SCREEN) {
-      an[1] = *(const f32x4*)(Ab + 128);
-      an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
-    }
+    an[1] = *(const f32x4*)(Ab + 128);
+    an[3] = *(const f32x4*)(Ab + 32 * ST_LDA + 128);
   }
   for (int g0 = 0; g0 < total; g0 += R) {
     if ((g0 & (SPB - 1)) == 0) bnext = bias_of(g0 / SPB + 1);
@@ -180,16 +169,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int kg = (g0 + j) & (SPB - 1);
-      if (H && SCREEN) {
-        const h8 bh = as_h8(ring[j]);
-        ring[j] = wload(g0 + j + R, 0);
-        const h8 a0h = as_h8(an[0]), a1h = as_h8(an[2]);
-        const int kn = (kg + 1) & (SPB - 1);
-        an[0] = *(const f32x4*)(Ab + kn * 8);
-        an[2] = *(const f32x4*)(Ab + 32 * ST_LDA + kn * 8);
-        acc0 = mfma16h(a0h, bh, acc0);
-        acc1 = mfma16h(a1h, bh, acc1);
-      } else if (H) {
+      if (H) {
         const h8 bh = as_h8(ring[j]), bl = as_h8(ringl[j]);
         ring[j] = wload(g0 + j + R, 0);
         ringl[j] = wload(g0 + j + R, 1);
@@ -323,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
           t = top2_merge(t, u);
         }
         a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] =
-            make_float4(t.m1, __int_as_float(t.i1), t.m2, SCREEN ? rownorm[tid] : 0.0f);
+            make_float4(t.m1, __int_as_float(t.i1), t.m2, 0.0f);
       } else {
         Lse t = {red[tid * 4 + 0], red[tid * 4 + 1]};
         float tg = red[tid * 4 + 2];
@@ -373,16 +353,10 @@ static int launch_rp_t(const GemmArgs& a, int n_bound, int splits, hipStream_t s
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
-static int launch_rp_argmax_screen(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
-  ST_ENSURE_LDS((rp_gemm_kernel<EPI_ARGMAX, 4, true, true>), RP_LDS);
-  if (n_bound <= 0) return ST_OK;
-  hipLaunchKernelGGL((rp_gemm_kernel<EPI_ARGMAX, 4, true, true>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
-  ST_LAUNCH_CHECK();
-  return ST_OK;
-}
 // ------------------------------------------------------------------------------------------------
 // Screening pass, software-pipelined form (the one st_decode.hip uses; grid = panels x column splits).
-// Ablations of the SCREEN path above (kbench, 229 k rows): without the top-2 bookkeeping the pass takes 38 % less
+// Ablations of the first form of this pass (the generic row-panel kernel with one product per step and a running
+// top-2 per logit; kbench, 229 k rows): without the top-2 bookkeeping the pass takes 38 % less
 // time, without the W loads 17 %, without the LDS reads 6 % - the 4 VALU operations per logit do not overlap with
 // the MFMAs, because a wave's bookkeeping for a block can only start when its last MFMA is done and there are just
 // two waves per SIMD.  Here the bookkeeping of block i-1 is interleaved, in one basic block, with the 32 MFMAs of

@@ -100,8 +100,6 @@ int main(int argc, char** argv) {
     g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
     const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(n, V, 16);
-    t = timeit([&] { launch_rp_argmax_screen(g, n, sp, st); });
-    printf("gen screen n=%d splits=%d: %8.1f us %6.1f TF (one product)\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
     t = timeit([&] { launch_rp_screen_pipelined(g, n, sp, st); });
     printf("gen screen, pipelined bookkeeping n=%d: %8.1f us %6.1f TF (one product)\n", n, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
   }
