@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
 // head: its K and V slices stay in registers for all queries.  Per query: q.k partial sums are reduced over the
 // 16 lanes of a key group with DPP rotations, the softmax max / sum and the PV partial sums are combined over
 // the four groups with two xor-shuffles each.  qkv rows: [q | k | v] (768 floats).
+template <bool FAST>  // as in enc_attn16_kernel below
 __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
                                                        float* __restrict__ out) {
   const int s = blockIdx.x;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < 16; ++t)
       if (t < nk) {
-        const float e = expf(sc[t] - m);
+        const float e = FAST ? __expf(sc[t] - m) : expf(sc[t] - m);
         sum += e;
         o4 += e * vr[t];
       }
@@ -80,6 +81,10 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
 // 4l..4l+3 (head l >> 4) of every K and V row of the sentence in registers (coalesced 1 KiB row loads); for each
 // query the q.k partial sums are reduced over the 16 lanes of a head with DPP row rotations, so the softmax and
 // the PV sum need no further lane traffic (same scheme as attn_step16_kernel in st_decode.hip).
+// FAST (f16x3 format): exp through v_exp_f32 (x * log2 e, ~1 ulp + |x| 2^-24) instead of the library's correctly
+// rounded expf, whose ~20 instructions per call were a quarter of this kernel (encoder setup 87 -> 84 ms per step);
+// the exact-f32 format keeps expf.
+template <bool FAST>
 __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
                                                          int n_sent, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       if (j < len) {
-        sc[j] = expf(sc[j] - m);
+        sc[j] = FAST ? __expf(sc[j] - m) : expf(sc[j] - m);
         sum += sc[j];
       }
     const float inv = 1.0f / sum;
@@ -200,8 +205,16 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       ST_TRY(launch_rp_lin_pipelined<EPI_BIAS>(g, R, qsplits, st));
     else
       ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, qsplits, st)));
-    hipLaunchKernelGGL(enc_attn16_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
-    if (max_sent_len > 16) hipLaunchKernelGGL(enc_attn_kernel, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+    if (w->gemm_format == ST_GEMM_F16X3)
+      hipLaunchKernelGGL(enc_attn16_kernel<true>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
+    else
+      hipLaunchKernelGGL(enc_attn16_kernel<false>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
+    if (max_sent_len > 16) {
+      if (w->gemm_format == ST_GEMM_F16X3)
+        hipLaunchKernelGGL(enc_attn_kernel<true>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+      else
+        hipLaunchKernelGGL(enc_attn_kernel<false>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+    }
     ST_LAUNCH_CHECK();
     OFArgs of = {};
     of.fmt = w->gemm_format; of.range_flag = range_flag;
