@@ -144,6 +144,8 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
 // to head l >> 4); q.k partial sums are reduced over the 16 lanes of a head with DPP row shifts, so every lane
 // of a head ends up with all of that head's scores and the softmax needs no further lane traffic; the PV sum
 // is lane-local.  All 2(pos+1) loads of a row are independent and issued up front.
+// FAST (f16x3 format): softmax exponential through v_exp_f32 (as in the encoder's attention, st_encode.hip).
+template <bool FAST>
 __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
                                                           const float* __restrict__ vbase, long kv_stride,
                                                           const int* __restrict__ idx, const int* __restrict__ n_dev,
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < 16; ++j)
     if (j <= pos) {
-      sc[j] = expf(sc[j] - m);
+      sc[j] = FAST ? __expf(sc[j] - m) : expf(sc[j] - m);
       sum += sc[j];
     }
   const float inv = 1.0f / sum;
@@ -428,8 +430,11 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         ST_TRY(launch_rp_lin_pipelined<EPI_QKV>(g, n_bound, qsplits, st));  // stores of block i-1 inside the MFMAs of block i
       else
         ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, qsplits, st)));
-      if (pos < 16)
-        hipLaunchKernelGGL(attn_step16_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
+      if (pos < 16 && w->gemm_format == ST_GEMM_F16X3)
+        hipLaunchKernelGGL(attn_step16_kernel<true>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
+                           n_dev, pos, ws.att);
+      else if (pos < 16)
+        hipLaunchKernelGGL(attn_step16_kernel<false>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
                            n_dev, pos, ws.att);
       else
         hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
