@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-decode", default="12,6", help="edit iterations decoded per round: an int or a schedule like 9,5,4")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--sync-every", type=int, default=None, help="decode steps between two host reads of the live count (default: the package's)")
     ap.add_argument("--distinct-batches", action="store_true",
                     help="a different synthetic batch for every warm-up and timed step (BASELINE config 4: --steps 31 = 1 M distinct "
                          "origins per GPU), all resident in HBM before the timed region; default: one batch reused")
@@ -116,6 +117,8 @@ def main():
     cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, early_exit=not a.fixed_steps,
                        iters_per_decode=(int(a.iters_per_decode) if "," not in a.iters_per_decode
                                          else tuple(int(v) for v in a.iters_per_decode.split(","))))
+    if a.sync_every is not None:
+        cfg.sync_every = a.sync_every
     runner = AttackRunner(ae, scorer, cfg, dev)
     B = a.batch
     from style_transfer_amd.data import load_word_counts

@@ -46,7 +46,8 @@ class AttackConfig:
     neg_victim_lr: float = 0.25
     # build-side knobs (no reference counterpart)
     early_exit: bool = True        # stop decoding a sentence at its first EOS/PAD (output-equivalent)
-    sync_every: int = 1
+    sync_every: int = 3            # decode steps between two host reads of the live count (kernels read it on the
+                                   # device every step; a stale, larger bound only launches workgroups that exit at once)
     log_decodes: bool = True       # the 1+10+10 decodes behind the Rec:/Sim:/Ref: log lines
     want_gap: bool = False
     want_trace: bool = False       # keep latents / grads / losses per iteration (parity tests)
