@@ -22,9 +22,17 @@ extern "C" int st_abi_version(void) { return 3; }
 int g_prof_on = 0;  // ST_PROF_*: which kernel's launches are bracketed (also read by st_encode.hip)
 static std::vector<ProfPair> g_prof;       // recorded pairs
 static std::vector<ProfPair> g_prof_free;  // recycled events
+static double* g_prof_acc = nullptr;       // device: algorithmic flops of the bracketed launches (actual live rows)
+__global__ void prof_tap_kernel(const int* n_dev, int n_host, double per_row, double* acc) {
+  *acc += (double)(n_dev ? *n_dev : n_host) * per_row;  // one thread, stream-ordered: no atomic needed
+}
 
 extern "C" int st_profile_enable(int which) {
   ST_CHECK_ARG(which >= ST_PROF_OFF && which <= ST_PROF_HALF_LAYER, "st_profile_enable: which=%d", which);
+  if (which != ST_PROF_OFF && !g_prof_acc) {
+    ST_HIP(hipMalloc(&g_prof_acc, sizeof(double)));
+    ST_HIP(hipMemset(g_prof_acc, 0, sizeof(double)));
+  }
   g_prof_on = which;
   return ST_OK;
 }
@@ -35,18 +43,19 @@ extern "C" int st_profile_read(double* gen_ms, double* gen_flops, long long* gen
     float t = 0.0f;
     ST_HIP(hipEventElapsedTime(&t, p.a, p.b));
     ms += t;
-    fl += p.flops;
   }
+  if (g_prof_acc) ST_HIP(hipMemcpy(&fl, g_prof_acc, sizeof(double), hipMemcpyDeviceToHost));
   if (gen_ms) *gen_ms = ms;
   if (gen_flops) *gen_flops = fl;
   if (gen_launches) *gen_launches = (long long)g_prof.size();
   if (reset) {
     for (auto& p : g_prof) g_prof_free.push_back(p);
     g_prof.clear();
+    if (g_prof_acc) ST_HIP(hipMemset(g_prof_acc, 0, sizeof(double)));
   }
   return ST_OK;
 }
-int prof_begin(ProfPair* p, double flops, hipStream_t st) {
+int prof_begin(ProfPair* p, double per_row, const int* n_dev, int n_host, hipStream_t st) {
   if (!g_prof_free.empty()) {
     *p = g_prof_free.back();
     g_prof_free.pop_back();
@@ -54,7 +63,9 @@ int prof_begin(ProfPair* p, double flops, hipStream_t st) {
     ST_HIP(hipEventCreate(&p->a));
     ST_HIP(hipEventCreate(&p->b));
   }
-  p->flops = flops;
+  p->flops = per_row * n_host;  // host-side bound, informational
+  hipLaunchKernelGGL(prof_tap_kernel, dim3(1), dim3(1), 0, st, n_dev, n_host, per_row, g_prof_acc);
+  ST_LAUNCH_CHECK();
   ST_HIP(hipEventRecord(p->a, st));
   return ST_OK;
 }
@@ -448,7 +459,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       if (w->gemm_format == ST_GEMM_F16X3 && n_bound >= RP_TAIL_MIN_ROWS) {
         ProfPair pt;
         if (g_prof_on == ST_PROF_HALF_LAYER)
-          ST_TRY(prof_begin(&pt, 2.0 * (double)n_bound * 256.0 * (256.0 + 2.0 * (double)w->d_ff), st));
+          ST_TRY(prof_begin(&pt, 2.0 * 256.0 * (256.0 + 2.0 * (double)w->d_ff), n_dev, n_bound, st));
         ST_TRY(launch_layer_tail(of, n_bound, st));  // O-projection + FFN in one kernel
         if (g_prof_on == ST_PROF_HALF_LAYER) ST_TRY(prof_end(&pt, st));
         continue;
@@ -495,7 +506,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     // (a vocabulary beyond 32768 would not fit the block number into the screening kernel's 8 key bits: no screening)
     const bool screen = screen_ok && n_bound >= ST_SCREEN_MIN_ROWS && (w->vocab + 127) / 128 <= RS_MAX_BLOCKS;
     ProfPair pp;
-    if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_begin(&pp, 2.0 * (double)n_bound * 256.0 * (double)w->vocab, st));
+    if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_begin(&pp, 2.0 * 256.0 * (double)w->vocab, n_dev, n_bound, st));
     if (screen) {
       // pass 1: one-product logits for every live row; rows with a clear winner are finished
       ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs

@@ -238,7 +238,9 @@ struct ProfPair {
   double flops;
 };
 extern int g_prof_on;
-int prof_begin(ProfPair* p, double flops, hipStream_t st);
+// flops = per_row * (the live row count read ON THE DEVICE when the launch runs: *n_dev, or n_host when n_dev is null) —
+// the host's row bound may be stale (st_decode_greedy reads the count only every few steps)
+int prof_begin(ProfPair* p, double per_row, const int* n_dev, int n_host, hipStream_t st);
 int prof_end(ProfPair* p, hipStream_t st);
 
 #define ST_TRY(x)            \
