@@ -222,7 +222,7 @@ def main():
                        "distinct_batches": bool(a.distinct_batches), "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
                        "mean_edit_iterations_per_sentence": n_iter_mean,
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
-                       "iters_per_decode": cfg.iters_per_decode, "gemm_format": a.gemm_format,
+                       "iters_per_decode": cfg.iters_per_decode, "sync_every": cfg.sync_every, "gemm_format": a.gemm_format,
                        "same_workload_exact_f32_format_sentences_per_s": f32_value,
                        "edit_iteration_units_per_s": world * units / dt},
             # achieved = ALGORITHMIC flops of the timed kernel / its HIP-event time.  f16x3 issues 3 MFMA flops per
