@@ -175,6 +175,20 @@ int st_gemm_argmax(const float* h, const float* ln_a, const float* ln_b, const f
                    const float* b, int n, int V, int gemm_format, int32_t* ids, float* best, float* gap,
                    void* scratch, void* stream);
 
+/* (3b) st_gemm_argmax for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that may not call hipMalloc or hand over a workspace — code under HIP graph capture, tight serving
+ * loops, harnesses that forbid allocation.  Same arguments and results as st_gemm_argmax minus `scratch`: the
+ * per-split partials go to a static device array inside the library (ST_NOALLOC_MAX_ROWS * ST_ARGMAX_SPLITS * 16
+ * bytes = 4 MiB per GPU the library runs on, held until the process ends).  n > ST_NOALLOC_MAX_ROWS returns
+ * ST_EINVAL.  The call allocates nothing (no hipMalloc / hipFree / allocating library routine); its first use on
+ * a device resolves that device's copy of the array with hipGetSymbolAddress.  All calls on one GPU share the
+ * array: calls that overlap on one GPU (two streams, two threads) race — serialise them.  Nothing in the array
+ * needs clearing between calls (every partial that is read was written by the same call).                  */
+#define ST_NOALLOC_MAX_ROWS 65536
+int st_gemm_argmax_noalloc(const float* h, const float* ln_a, const float* ln_b, const float* W,
+                           const float* b, int n, int V, int gemm_format, int32_t* ids, float* best, float* gap,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (4) Text-change detection (siamese_contrastive.py:816-839 + data.py:43-52), on ids.
  * For each active sentence: the decoded row `new_ids` and the accepted row `acc_ids` are compared

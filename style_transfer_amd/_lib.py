@@ -9,13 +9,14 @@ LIB_PATH = os.environ.get("ST_KERNELS_LIB") or os.path.join(HERE, "libst_kernels
 ST_MAX_LAYERS = 4
 ST_MAX_REFS = 16
 ST_ARGMAX_SPLITS = 4
+ST_NOALLOC_MAX_ROWS = 65536
 ST_F_NOT_NLL, ST_F_SIMPLEST, ST_F_JUST_USE_ONE = 1, 2, 4
 ST_DEC_EARLY_EXIT = 1
 ST_DEC_NO_SCREEN = 2
 ST_PROF_OFF, ST_PROF_GENERATOR, ST_PROF_HALF_LAYER = 0, 1, 2
 ST_GEMM_F32, ST_GEMM_F16X3 = 0, 1
 GEMM_FORMATS = {"f32": ST_GEMM_F32, "f16x3": ST_GEMM_F16X3}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -73,6 +74,7 @@ EXPORTS = {
     "st_decode_greedy": (C.c_int, [C.POINTER(StDecoderWeights), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, fp, fp, fp, C.c_size_t, C.POINTER(C.c_int), fp]),
     "st_gemm_argmax": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp]),
+    "st_gemm_argmax_noalloc": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]),
     "st_accept_changes": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp,
                                     fp, fp, fp, fp, fp]),
     "st_simloss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),

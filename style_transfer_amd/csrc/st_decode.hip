@@ -15,7 +15,7 @@ void st_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 3; }
+extern "C" int st_abi_version(void) { return 4; }
 
 // ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
 #include <vector>
@@ -581,6 +581,42 @@ extern "C" int st_gemm_argmax(const float* h, const float* ln_a, const float* ln
                      ST_ARGMAX_SPLITS, n, ids, best, gap);
   ST_LAUNCH_CHECK();
   return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// st_gemm_argmax without any allocation and without a caller-supplied scratch buffer: the per-split
+// partials live in a file-scope device array.  Every GPU holds its own copy of the array at its own
+// address, so the address is looked up once per device (hipGetSymbolAddress with that device current)
+// and host code only ever uses that pointer, never the array's name.
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[(size_t)ST_NOALLOC_MAX_ROWS * ST_ARGMAX_SPLITS * 16];
+static void* g_scratch_ptr[ST_MAX_DEVICES] = {};
+
+static int scratch_for_current_device(void** out) {
+  int dev = 0;
+  ST_HIP(hipGetDevice(&dev));
+  ST_CHECK_ARG(dev >= 0 && dev < ST_MAX_DEVICES, "device ordinal %d out of range", dev);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    ST_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    ST_CHECK_ARG(p != nullptr, "hipGetSymbolAddress returned a null address for the scratch array");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return ST_OK;
+}
+
+extern "C" int st_gemm_argmax_noalloc(const float* h, const float* ln_a, const float* ln_b, const float* W,
+                                      const float* b, int n, int V, int gemm_format, int32_t* ids, float* best,
+                                      float* gap, void* stream) {
+  ST_CHECK_ARG(n >= 0 && n <= ST_NOALLOC_MAX_ROWS,
+               "st_gemm_argmax_noalloc: n=%d exceeds the static scratch (ST_NOALLOC_MAX_ROWS=%d rows); "
+               "split the call or use st_gemm_argmax with a caller-owned scratch buffer",
+               n, ST_NOALLOC_MAX_ROWS);
+  void* sp = nullptr;
+  ST_TRY(scratch_for_current_device(&sp));
+  // every (row < n, split) partial is rewritten by the GEMM before the merge reads it: nothing has to start at zero
+  return st_gemm_argmax(h, ln_a, ln_b, W, b, n, V, gemm_format, ids, best, gap, sp, stream);
 }
 
 extern "C" size_t st_packed_weight_floats(int N, int K) { return (N > 0 && K > 0 && K % 8 == 0) ? rp_packed_floats(N, K) : 0; }

@@ -150,6 +150,17 @@ def gemm_argmax(h, W, b, ln_a=None, ln_b=None, packed=None, gemm_format="f32"):
     return ids, best, gap
 
 
+def gemm_argmax_noalloc(h, packed, b, ids, best, gap, ln_a=None, ln_b=None, gemm_format="f32"):
+    """st_gemm_argmax_noalloc: every buffer (inputs AND outputs) comes from the caller, the scratch is the library's
+    static device array; this wrapper allocates nothing either.  n <= _lib.ST_NOALLOC_MAX_ROWS."""
+    _f32(h); _f32(b); _f32(best); _f32(gap)
+    n, V = h.shape[0], b.shape[0]
+    assert h.shape[1] == 256 and ids.dtype == torch.int32 and ids.numel() >= n and best.numel() >= n and gap.numel() >= n
+    check(lib().st_gemm_argmax_noalloc(h.data_ptr(), _p(ln_a), _p(ln_b), packed.data_ptr(), b.data_ptr(), n, V,
+                                       _fmt(gemm_format), ids.data_ptr(), best.data_ptr(), gap.data_ptr(), _stream()),
+          "st_gemm_argmax_noalloc")
+
+
 def accept_changes(new_ids, acc_ids, vocab, n_changes, changed, active, max_change=7, unk=1, eos=3, pad=0,
                    canon=None, rec_ids=None, confirm_ids=None):
     B, T = new_ids.shape
