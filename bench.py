@@ -4,15 +4,18 @@
 A "step" is one pass of the hot path (encode 1+10+10 sentences, like/unlike scorer embeddings, initial
 decode, then up to 18 edit iterations of scorer fwd/bwd/Adam + greedy decode + change detection) over
 one batch of synthetic yelp-shaped sentences per GPU, with the packed token arrays already resident
-in HBM.  Sentences are independent, so ranks share nothing (weak scaling: fixed batch per GPU).
+in HBM.  Sentences are independent, so ranks share nothing (weak scaling: fixed batch per GPU).  Every
+warm-up and timed step runs a DIFFERENT synthetic batch (BASELINE config 4: --steps 31 = 1 M distinct
+origins per GPU).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        # N > 1 without a launcher: spawns one process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -63,7 +66,7 @@ def cpu_baseline(seconds_budget=20.0, shape="yelp"):
                        "(BASELINE.md, yelp)") % (done, shape, dt)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -74,29 +77,90 @@ def main():
                     help="synthetic token ids: unigram (Zipfian) from word_to_id.txt counts, uniform in [4,V), or the "
                          "1000 real yelp test sentences tiled to the batch size")
     ap.add_argument("--fixed-steps", action="store_true", help="no early exit at EOS: always 59 decode steps")
+    ap.add_argument("--log-decodes", action="store_true", help="include the 1+10+10 Rec/Sim/Ref log decodes in the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-decode", default="12,6", help="edit iterations decoded per round: an int or a schedule like 9,5,4")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--sync-every", type=int, default=None, help="decode steps between two host reads of the live count (default: the package's)")
-    ap.add_argument("--distinct-batches", action="store_true",
-                    help="a different synthetic batch for every warm-up and timed step (BASELINE config 4: --steps 31 = 1 M distinct "
-                         "origins per GPU), all resident in HBM before the timed region; default: one batch reused")
-    ap.add_argument("--no-f32-reference-run", action="store_true",
-                    help="skip the short exact-f32-format run that is reported beside the f16x3 value")
+    ap.add_argument("--same-batch", action="store_true",
+                    help="reuse ONE synthetic batch for every step (round-1 behaviour); default: a different batch per step, all "
+                         "resident in HBM before the timed region")
+    ap.add_argument("--no-side-runs", action="store_true",
+                    help="skip the short extra runs reported in config (exact-f32 format, fixed 59 steps, log decodes on, end to end)")
     ap.add_argument("--gemm-format", default="f16x3", choices=["f16x3", "f32"],
                     help="operand format of the AE weight GEMMs: 3-product f16 split (f32-grade results) or exact f32 MFMA")
-    a = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control-flow rehearsal without a GPU: launch, rendezvous (gloo), barrier, max-over-ranks timing and the "
+                         "one JSON line; no kernel runs and `value` is null")
+    return ap.parse_args(argv)
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start one fresh worker process per GPU (before
+    this process has made any GPU call), with the rendezvous variables torch.distributed.run would set; rank 0 prints the
+    JSON line on the inherited stdout."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def algorithmic_flops(ae, B_total, units, enc_rows, enc_sq, kp, kn, work):
+    """minimal formulation (KV cache, cross-attention folded, no log-softmax).
+    work = (token_steps, keys_attended, decode_jobs) counted on the device."""
+    d, dff, N, V = 256, ae.d_ff, ae.n_layers, ae.vocab
+    layer = 2.0 * N * (4 * d * d + 2 * d * dff)
+    tok, keys, jobs = work
+    decode = tok * (layer + 2.0 * d * V) + keys * (2.0 * N * 2 * d) + jobs * (2.0 * N * 2 * d * d)
+    encode = enc_rows * layer + enc_sq * (4.0 * N * d)
+    scorer_mac = 256 * 512 + 512 * 512 + 512 * 256
+    scorer = units * 2.0 * 2.0 * 575488 + B_total * (kp + kn) * 2.0 * scorer_mac
+    return dict(decode=decode, encode=encode, scorer=scorer, total=decode + encode + scorer)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a, argv)
 
     import torch
     import torch.distributed as dist
-    from style_transfer_amd import _lib, weights as W
-    from style_transfer_amd.attack import AttackConfig, AttackRunner
-    from style_transfer_amd.data import AttackSet
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+    assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
+    if a.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "style-transferred sentences/sec, yelp-shape", "value": None, "unit": "sentences/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(tt.item()) * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "dry run: no kernels", "dry_run": True}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    from style_transfer_amd import _lib, weights as W
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet, load_word_counts, load_word_dict_info
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # one rank per GPU; ST_BENCH_BACKEND=gloo (rehearsal of the N > 1 control flow on a box with fewer GPUs than
     # ranks) maps the ranks onto the visible devices round-robin and reduces the timing on the CPU
@@ -110,48 +174,65 @@ def main():
             dist.init_process_group(backend)
 
     # yelp shape: V = 9339; amazon shape: V = 19724 with its own surrogate AE (no amazon weights ship at all)
-    ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)), dev,
-                     gemm_format=a.gemm_format)
+    ae_file = os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)
+    ae = W.AEWeights(W.load_state_dict_file(ae_file), dev, gemm_format=a.gemm_format)
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
                              W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
-    cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, early_exit=not a.fixed_steps,
-                       iters_per_decode=(int(a.iters_per_decode) if "," not in a.iters_per_decode
-                                         else tuple(int(v) for v in a.iters_per_decode.split(","))))
+    ipd = int(a.iters_per_decode) if "," not in a.iters_per_decode else tuple(int(v) for v in a.iters_per_decode.split(","))
+    cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=a.log_decodes, early_exit=not a.fixed_steps,
+                       iters_per_decode=ipd)
     if a.sync_every is not None:
         cfg.sync_every = a.sync_every
     runner = AttackRunner(ae, scorer, cfg, dev)
     B = a.batch
-    from style_transfer_amd.data import load_word_counts
+    counts = None
     if a.tokens == "real":
         files = [os.path.join(GOLD, a.shape, "neg10_pos10_test%d.json" % i) for i in (0, 1)]
         real = AttackSet.from_json(files, ae.vocab)
-        data = real.subset([(i + 137 * rank) % len(real) for i in range(B)])
+        make = lambda k: real.subset([(i + 137 * rank + 7919 * k) % len(real) for i in range(B)])
     else:
         counts = load_word_counts(os.path.join(GOLD, a.shape, "word_to_id.txt"), ae.vocab) if a.tokens == "zipf" else None
-        data = AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank, word_counts=counts)
-    prep = runner.prepare(data)                       # tokens resident in HBM before the timed region
-    preps = [prep] * (a.warmup + a.steps)
-    if a.distinct_batches:
-        if a.tokens == "real":
-            raise SystemExit("--distinct-batches needs synthetic tokens")
-        for k in range(1, a.warmup + a.steps):
-            preps[k] = runner.prepare(AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank + 7919 * k, word_counts=counts))
-            if rank == 0 and k % 4 == 0:
-                print("[bench] generated batch %d of %d" % (k + 1, a.warmup + a.steps), file=sys.stderr, flush=True)
+        make = lambda k: AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + rank + 7919 * k, word_counts=counts)
+    n_run = a.warmup + a.steps
+    sets = [make(0)] * n_run if a.same_batch else [make(k) for k in range(n_run)]
+    preps = [runner.prepare(sets[0])] * n_run if a.same_batch else [runner.prepare(s) for s in sets]   # resident in HBM
     gidx = torch.arange(B, device=dev) % 1000
+    # encoder work of the timed steps (host-known): token rows and sum of squared sentence lengths
+    enc_rows = enc_sq = 0
+    for s in sets[a.warmup:]:
+        for r in (s.origin_r, s.like_r, s.unlike_r):
+            ln = r.lens.astype(np.float64)
+            enc_rows += float(ln.sum())
+            enc_sq += float((ln * ln).sum())
+    kp, kn = sets[0].n_pos, sets[0].n_neg
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def reduce_max(x):
+        t = torch.tensor([x], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(xs):
+        t = torch.tensor(xs, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
     L = _lib.lib()
+    work = (C.c_ulonglong * 4)()
     for k in range(a.warmup):
         runner.run_prepared(preps[k], gidx, fetch=False)
     sync()
+    L.st_work_counters_read(work, 1)
     L.st_profile_enable(_lib.ST_PROF_HALF_LAYER if a.gemm_format == "f16x3" else _lib.ST_PROF_GENERATOR)
     units = 0
     setup_s = loop_s = 0.0
+    n_iter_sum = 0.0
     t0 = time.perf_counter()
     for k in range(a.steps):
         r = runner.run_prepared(preps[a.warmup + k], gidx, fetch=False)
@@ -163,32 +244,83 @@ def main():
     L.st_profile_enable(0)
     gen_ms, gen_fl, gen_n = C.c_double(), C.c_double(), C.c_longlong()
     L.st_profile_read(C.byref(gen_ms), C.byref(gen_fl), C.byref(gen_n), 1)
+    L.st_work_counters_read(work, 1)
     n_iter_mean = float(r.device["was_active"].sum().item()) / B
+    del r
+    dt = reduce_max(dt)
+    tot = reduce_sum([float(work[0]), float(work[1]), float(work[2]), float(units), enc_rows, enc_sq])
 
-    # The same workload once more in the exact-f32 operand format (2 steps after 1 warm-up), reported beside
-    # `value` so that the cost / benefit of the split format can be read from one line.
-    f32_value = None
-    if a.gemm_format == "f16x3" and not a.no_f32_reference_run:
-        del r
-        runner.ws.buf = None
-        torch.cuda.empty_cache()
-        ae32 = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)), dev,
-                           gemm_format="f32")
-        runner32 = AttackRunner(ae32, scorer, cfg, dev)
-        runner32.run_prepared(prep, gidx, fetch=False)
-        sync()
-        t32 = time.perf_counter()
-        for _ in range(2):
-            runner32.run_prepared(prep, gidx, fetch=False)
-        sync()
-        d32 = torch.tensor([time.perf_counter() - t32], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(d32, op=dist.ReduceOp.MAX)
-        f32_value = world * B * 2 / float(d32.item())
-    tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    # ---- side runs (one GPU only): the same workload under the other configurations SURVEY 8d asks to report ----
+    side = {}
+    if world == 1 and not a.no_side_runs and a.gemm_format == "f16x3" and not a.fixed_steps and not a.log_decodes:
+        def timed(rn, pp, n=2):
+            rn.run_prepared(pp[0], gidx[:pp[0]["B"]], fetch=False)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for i in range(n):
+                rn.run_prepared(pp[i % len(pp)], gidx[:pp[0]["B"]], fetch=False)
+            torch.cuda.synchronize(dev)
+            return pp[0]["B"] * n / (time.perf_counter() - t)
+
+        def fresh():
+            runner.ws.buf = None
+            torch.cuda.empty_cache()
+        # (1) exact-f32 operand format, same batches
+        fresh()
+        ae32 = W.AEWeights(W.load_state_dict_file(ae_file), dev, gemm_format="f32")
+        r32 = AttackRunner(ae32, scorer, cfg, dev)
+        side["exact_f32_format_sentences_per_s"] = timed(r32, preps[:2])
+        r32.ws.buf = None
+        del r32, ae32
+        fresh()
+        # (2) no early exit: the reference's fixed 59 decode steps (batch 16384: the f32 KV cache of 13 jobs x 59 keys)
+        Bs = min(B, 16384)
+        small = [runner.prepare(s.span(0, Bs)) for s in sets[:2]]
+        cfgf = AttackConfig(**{**cfg.__dict__, "early_exit": False})
+        rf = AttackRunner(ae, scorer, cfgf, dev)
+        side["fixed_59_decode_steps_sentences_per_s"] = timed(rf, small, 1)
+        side["fixed_59_decode_steps_batch"] = Bs
+        rf.ws.buf = None
+        del rf
+        fresh()
+        # (3) with the 1+10+10 Rec/Sim/Ref log decodes (batch 8192: 20 more decode jobs per sentence)
+        Bl = min(B, 8192)
+        smalll = [runner.prepare(s.span(0, Bl)) for s in sets[:2]]
+        cfgl = AttackConfig(**{**cfg.__dict__, "log_decodes": True})
+        rl = AttackRunner(ae, scorer, cfgl, dev)
+        side["with_log_decodes_sentences_per_s"] = timed(rl, smalll, 2)
+        rl2 = AttackRunner(ae, scorer, cfg, dev)
+        side["without_log_decodes_same_batch_sentences_per_s"] = timed(rl2, smalll, 2)
+        side["log_decodes_batch"] = Bl
+        rl.ws.buf = rl2.ws.buf = None
+        del rl, rl2
+        fresh()
+        # (4) end to end: token arrays on the HOST -> pack -> H2D -> attack -> compact records D2H -> log text -> file,
+        # software-pipelined over the batches (style_transfer_amd/pipeline.py), the product CLI's path
+        import tempfile
+        from style_transfer_amd.logfmt import LogWriter, VocabBytes, format_attack_block
+        from style_transfer_amd.pipeline import run_shard
+        from style_transfer_amd.data import Ragged
+        id_to_word, _ = load_word_dict_info(os.path.join(GOLD, a.shape, "word_to_id.txt"), 5)
+        vocab = VocabBytes(id_to_word)
+        n_e2e = min(len(sets), 4) if not a.same_batch else 1
+        big = AttackSet(Ragged.concat([s.origin_r for s in sets[:n_e2e]]), Ragged.concat([s.like_r for s in sets[:n_e2e]]),
+                        Ragged.concat([s.unlike_r for s in sets[:n_e2e]]), None, kp, kn)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "log")
+            for rep in range(2):      # first pass warms the pinned buffers and threads
+                log = LogWriter(path, echo=False)
+                consume = lambda b0, b1, lean: log.write_block(format_attack_block(vocab, big.span(b0, b1), lean.to("cpu", pinned=True), b0))
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                run_shard(runner, big, 0, len(big), B, consume)
+                log.close()
+                e2e = len(big) / (time.perf_counter() - t)
+                nbytes = os.path.getsize(path)
+        side["end_to_end_sentences_per_s"] = e2e
+        side["end_to_end_note"] = ("%d sentences in batches of %d: host token arrays -> pack -> H2D -> attack -> changed rows D2H -> "
+                                   "log text (st_format_attack_log) -> file (%.0f MB), prefetch and drain threads overlapped "
+                                   "with compute" % (len(big), B, nbytes / 1e6))
 
     if rank == 0:
         achieved = gen_fl.value / (gen_ms.value * 1e-3) / 1e12 if gen_ms.value > 0 else 0.0
@@ -198,15 +330,19 @@ def main():
         # read from inside the process): profiles/README.md gives the two commands; tools/traffic_from_pmc.py applies
         # the guide's gfx950 correction.  Only quoted for the configuration the passes were made on.
         traffic = traffic_src = alg_bytes = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_bench_half_layer_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r02_pmc_bench_half_layer_traffic.json")
         if split and gen_n.value > 0:
             # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
             alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
             default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 32768 and not a.fixed_steps
-                           and a.iters_per_decode == "12,6")
+                           and a.iters_per_decode == "12,6" and not a.log_decodes)
             if default_cfg and os.path.exists(tfile):
                 traffic = json.load(open(tfile))["bytes_per_launch"]
-                traffic_src = "profiles/r01_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"
+                traffic_src = "profiles/r02_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"
+        fl = algorithmic_flops(ae, world * B * a.steps, tot[3], tot[4], tot[5], kp, kn, tot[:3])
+        whole = fl["total"] / dt / 1e12
+        # share of the algorithmic flops that run as AE matrix products (3 MFMA flops issued per flop in f16x3)
+        ae_share = (fl["decode"] + fl["encode"]) / fl["total"]
         out = {
             "metric": "style-transferred sentences/sec, yelp-shape" if a.shape == "yelp" else "style-transferred sentences/sec, amazon-shape",
             "value": world * B * a.steps / dt, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -215,16 +351,26 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d; token ids: %s), %d per GPU per step, flags --attack "
                                    "--not_nll --pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
-                                   "surrogate AE checkpoint + shipped (yelp) Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes off"
+                                   "surrogate AE checkpoint + shipped (yelp) Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes %s"
                                    % (a.shape, {"zipf": "unigram/Zipfian from word_to_id.txt counts", "uniform": "uniform in [4,V)",
                                                 "real": "the real yelp test set tiled"}[a.tokens], B,
-                                      "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS"),
-                       "distinct_batches": bool(a.distinct_batches), "batch_per_gpu": B, "sentences_per_step": world * B, "parallelism": "sentence-sharded x%d" % world,
+                                      "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS", "on" if a.log_decodes else "off"),
+                       "distinct_batches": not a.same_batch, "batch_per_gpu": B, "sentences_per_step": world * B,
+                       "parallelism": "sentence-sharded x%d" % world,
                        "mean_edit_iterations_per_sentence": n_iter_mean,
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
                        "iters_per_decode": cfg.iters_per_decode, "sync_every": cfg.sync_every, "gemm_format": a.gemm_format,
-                       "same_workload_exact_f32_format_sentences_per_s": f32_value,
-                       "edit_iteration_units_per_s": world * units / dt},
+                       "edit_iteration_units_per_s": tot[3] / dt,
+                       "side_runs_same_workload_one_gpu": side or None},
+            # the whole timed region against the MFMA roofline: executed algorithmic flops / wall time
+            "whole_step": {"executed_token_steps": tot[0], "keys_attended": tot[1], "decode_jobs_executed": tot[2],
+                           "decode_jobs_needed": world * B * a.steps + tot[3],
+                           "encoder_token_rows": tot[4],
+                           "algorithmic_flops": fl, "algorithmic_tflops": whole, "peak": peak, "frac": whole / peak,
+                           "mfma_issue_frac": whole * ((3 * ae_share + (1 - ae_share)) if split else 1) / peak,
+                           "note": "F_tok = 2[N(4d^2 + 2 d d_ff) + d V] + 2048 t per executed token-step (KV cache, cross-attention "
+                                   "folded, no log-softmax) + encoder + scorer; token-steps counted on the device from the live "
+                                   "counts; wall time includes every launch gap, host sync and the non-GEMM kernels"},
             # achieved = ALGORITHMIC flops of the timed kernel / its HIP-event time.  f16x3 issues 3 MFMA flops per
             # algorithmic flop, so frac <= 1/3 there by construction; mfma_issue_frac counts the issued ones.
             "roofline": {"bound": "mfma",
@@ -246,7 +392,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -56,6 +56,11 @@ const char* st_last_error(void);
 #define ST_PROF_HALF_LAYER 2
 int st_profile_enable(int which);
 int st_profile_read(double* ms, double* flops, long long* launches, int reset);
+/* Executed work on the current GPU since the last reset, counted on the device from the exact live counts (no
+ * reference counterpart; bench.py's whole-loop roofline): out4_host[0] = decode token-steps (live rows summed over
+ * the decode steps of every st_decode_greedy call), [1] = keys attended (sum of prefix lengths over those
+ * token-steps), [2] = decode jobs started, [3] reserved.  Synchronises the device.                                            */
+int st_work_counters_read(unsigned long long* out4_host, int reset);
 
 /* Weight packing (no reference counterpart).  The GEMM kernels read nn.Linear weight matrices
  * W [N,K] row-major in MFMA-fragment order so that every wave load is one coalesced 1 KiB read.
@@ -305,6 +310,26 @@ int st_scorer_train_step(const float* params, float* bn, const float* x, int B, 
 /* torch.optim.Adam with default options (no weight decay, no amsgrad) over n elements; step is 1-based.  */
 int st_adam_step(float* params, const float* grads, float* adam_m, float* adam_v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (9) HOST function (no GPU work, all pointers are host pointers): the per-sentence block of the log that
+ * attack_contrastive / contrastive_attack_one print (siamese_contrastive.py:702-732, :789, :825-836) with
+ * id2text_sentence (data.py:43-52), from the compact per-sentence records:
+ *   vocab_bytes / vocab_off [vocab+1]: the words of word_to_id.txt, concatenated (UTF-8)
+ *   prefix: what precedes every record in the log file ("INFO:siamese_contrastive.py:print_and_log:1592 - ")
+ *   src_tokens / src_off [S+1]: the origin sentences ('Src:' line)     init_ids [S,T]: 'Rec:' line
+ *   like_ids [S,kp,T] / unlike_ids [S,kn,T] or NULL: 'Sim{j}:' / 'Ref{j}:' lines
+ *   n_iter [S], changed [S,I] (1 = a 'Change.k' line precedes 'iteration.it'), rows [sum(changed),T]: the accepted
+ *   ids after each change, sentence-major; the text of 'iteration.it' is the last accepted one (init_ids before
+ *   the first change).   first_index: global index of sentence 0 ('Sentence Pair.{i}').
+ * Returns the number of bytes the block takes; it is written to `out` only if that is <= out_cap (call with
+ * out = NULL to size the buffer); -1 on a bad argument.  --dance blocks are formatted by the Python writer. */
+long long st_format_attack_log(const char* vocab_bytes, const int64_t* vocab_off, int vocab, int eos, int pad, int unk,
+                               const char* prefix, int S, int T, int I, long long first_index,
+                               const int32_t* src_tokens, const int64_t* src_off, const int32_t* init_ids,
+                               const int32_t* like_ids, int kp, const int32_t* unlike_ids, int kn,
+                               const int32_t* n_iter, const uint8_t* changed, const int32_t* rows, char* out,
+                               long long out_cap);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,7 @@ EXPORTS = {
     "st_last_error": (C.c_char_p, []),
     "st_profile_enable": (C.c_int, [C.c_int]),
     "st_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
+    "st_work_counters_read": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "st_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "st_pack_weight": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp]),
     "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
@@ -85,6 +86,9 @@ EXPORTS = {
     "st_scorer_train_step": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, fp, C.c_uint64,
                                        fp, fp, fp, fp, C.c_size_t, fp]),
     "st_adam_step": (C.c_int, [fp, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp]),
+    "st_format_attack_log": (C.c_longlong, [C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                            C.c_int, C.c_longlong, fp, fp, fp, fp, C.c_int, fp, C.c_int, fp, fp, fp, fp,
+                                            C.c_longlong]),
     "st_encode_latent": (C.c_int, [C.POINTER(StEncoderWeights), fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.c_size_t, fp]),
 }
 

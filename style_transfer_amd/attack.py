@@ -85,6 +85,87 @@ class AttackResult:
     dance: dict = None            # --dance: loss [S,I], scores [S,I,K+ + K-], n_pos, not_nll
 
 
+@dataclass
+class LeanRecord:
+    """The per-sentence records in the compact form that leaves the GPU and crosses ranks: the accepted text only
+    changes where `changed` is set, so instead of the dense [S,I,T] table (4.2 KB per sentence) only the rows of the
+    changes travel (<= attack_max_change rows of 236 B per sentence).  Fields are torch tensors on one device
+    (GPU after a run, CPU after .cpu()); expand() rebuilds the dense AttackResult."""
+    n_iter: torch.Tensor           # [S] int32
+    init_ids: torch.Tensor         # [S,T] int32
+    changed: torch.Tensor          # [S,I] uint8
+    rows: torch.Tensor             # [sum(changed),T] int32, sentence-major then iteration
+    like_ids: torch.Tensor = None  # [S,K+,T] (log_decodes)
+    unlike_ids: torch.Tensor = None
+    final_latent: torch.Tensor = None
+
+    FIELDS = ("n_iter", "init_ids", "changed", "rows", "like_ids", "unlike_ids", "final_latent")
+
+    def __len__(self):
+        return int(self.n_iter.shape[0])
+
+    @classmethod
+    def from_device(cls, d, want_latent=False):
+        """d: AttackResult.device of run_prepared(fetch=False)"""
+        n_iter = d["was_active"].sum(0, dtype=torch.int32)
+        I = d["changed"].shape[0]
+        changed = d["changed"].t().contiguous()
+        changed = changed * (torch.arange(I, device=changed.device)[None, :] < n_iter[:, None]).to(torch.uint8)
+        rows = d["iter_ids"].permute(1, 0, 2)[changed.bool()].contiguous()
+        return cls(n_iter, d["init_ids"], changed, rows, d.get("like_ids"), d.get("unlike_ids"),
+                   d["latent"] if want_latent else None)
+
+    def to(self, device, pinned=False):
+        def mv(t):
+            if t is None:
+                return None
+            if pinned and device == "cpu" and t.is_cuda:
+                buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                buf.copy_(t, non_blocking=True)
+                return buf
+            return t.to(device)
+        out = LeanRecord(*[mv(getattr(self, f)) for f in self.FIELDS])
+        if pinned and device == "cpu":
+            torch.cuda.current_stream().synchronize()
+        return out
+
+    def cpu(self):
+        return self.to("cpu")
+
+    @staticmethod
+    def cat(parts):
+        cat = lambda xs: None if any(x is None for x in xs) else torch.cat(xs, 0)
+        return LeanRecord(*[cat([getattr(p, f) for p in parts]) for f in LeanRecord.FIELDS])
+
+    @classmethod
+    def empty(cls, cfg, kp, kn, device="cpu", want_latent=False):
+        T = cfg.max_sequence_length - 1
+        I = 2 if cfg.dance else cfg.attack_max_iter
+        z = lambda *sh, dt=torch.int32: torch.zeros(sh, dtype=dt, device=device)
+        ids = lambda k: z(0, k, T) if (cfg.log_decodes and k) else None
+        return cls(z(0), z(0, T), z(0, I, dt=torch.uint8), z(0, T), ids(kp), ids(kn),
+                   z(0, 256, dt=torch.float32) if want_latent else None)
+
+    def expand(self) -> AttackResult:
+        """the dense records (numpy): iter_ids[s,it] = the last changed row at or before it, else init_ids[s]"""
+        r = self.cpu()
+        n_iter, init, ch, rows = r.n_iter.numpy(), r.init_ids.numpy(), r.changed.numpy(), r.rows.numpy()
+        S, I = ch.shape
+        T = init.shape[1]
+        cs = np.cumsum(ch.astype(np.int64), 1)
+        start = np.zeros(S, np.int64)
+        if S:
+            np.cumsum(cs[:-1, -1], out=start[1:])
+        if rows.shape[0]:
+            picked = rows[np.clip(start[:, None] + cs - 1, 0, rows.shape[0] - 1)]
+        else:
+            picked = np.zeros((S, I, T), np.int32)
+        it_ids = np.where((cs > 0)[:, :, None], picked, init[:, None, :])
+        it_ids = np.where((np.arange(I)[None, :] < n_iter[:, None])[:, :, None], it_ids, 0).astype(np.int32)
+        npy = lambda t: None if t is None else t.numpy()
+        return AttackResult(n_iter, init, it_ids, ch, npy(r.like_ids), npy(r.unlike_ids), npy(r.final_latent))
+
+
 class AttackRunner:
     def __init__(self, ae, scorer, cfg: AttackConfig, device):
         if cfg.victim_optimizer != "Adam":
@@ -104,13 +185,13 @@ class AttackRunner:
     def prepare(self, batch: AttackSet):
         """Host -> device: pack the 1 + K+ + K- sentences of every origin (order: all origins, all
         like groups, all unlike groups) into device token arrays, in chunks of ENC_CHUNK sentences."""
-        sents = list(batch.origin) + [s for grp in batch.like for s in grp] + [s for grp in batch.unlike for s in grp]
+        sents = batch.all_sentences()            # one flat token array + offsets (data.Ragged): no per-sentence Python
         dev, chunks = self.device, []
         for c0 in range(0, len(sents), self.ENC_CHUNK):
-            part = sents[c0:c0 + self.ENC_CHUNK]
-            tokens, tok_pos, sent_off, max_len = pack_sentences(part)
-            chunks.append((torch.from_numpy(tokens).to(dev), torch.from_numpy(tok_pos).to(dev),
-                           torch.from_numpy(sent_off).to(dev), len(part), max_len))
+            c1 = min(len(sents), c0 + self.ENC_CHUNK)
+            tokens, tok_pos, sent_off, max_len = pack_sentences(sents.span(c0, c1))
+            chunks.append((torch.from_numpy(tokens).to(dev, non_blocking=True), torch.from_numpy(tok_pos).to(dev, non_blocking=True),
+                           torch.from_numpy(sent_off).to(dev, non_blocking=True), c1 - c0, max_len))
         return dict(chunks=chunks, B=len(batch), kp=batch.n_pos, kn=batch.n_neg)
 
     def encode_prepared(self, prep):
@@ -300,7 +381,8 @@ class AttackRunner:
         tm["units"] = n_units
         res.timing = tm
         if not fetch:
-            res.device = dict(was_active=was_active, iter_ids=iter_ids, changed=changed, init_ids=init_ids, latent=final_latent)
+            res.device = dict(was_active=was_active, iter_ids=iter_ids, changed=changed, init_ids=init_ids, latent=final_latent,
+                              like_ids=like_ids_dev, unlike_ids=unlike_ids_dev)
             return res
         res.n_iter = was_active.sum(0).cpu().numpy().astype(np.int32)
         res.init_ids = init_ids.cpu().numpy()

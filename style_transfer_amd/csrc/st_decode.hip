@@ -75,6 +75,32 @@ int prof_end(ProfPair* p, hipStream_t st) {
   return ST_OK;
 }
 
+// ---- executed-work counters (bench.py's whole-loop roofline): a file-scope device array per GPU -------
+// [0] decode token-steps (live rows summed over decode steps)   [1] keys attended (sum of prefix lengths)
+// [2] decode jobs (rows at step 0)   [3] reserved.   Each GPU holds its own copy; its address is looked up once per device.
+static __device__ __align__(256) unsigned long long g_work_counters[4];
+static unsigned long long* g_work_ptr[ST_MAX_DEVICES] = {};
+int st_work_counters_ptr(unsigned long long** out) {
+  int dev = 0;
+  ST_HIP(hipGetDevice(&dev));
+  ST_CHECK_ARG(dev >= 0 && dev < ST_MAX_DEVICES, "device ordinal %d out of range", dev);
+  if (!g_work_ptr[dev]) {
+    void* p = nullptr;
+    ST_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_work_counters)));
+    g_work_ptr[dev] = (unsigned long long*)p;
+  }
+  *out = g_work_ptr[dev];
+  return ST_OK;
+}
+extern "C" int st_work_counters_read(unsigned long long* out4_host, int reset) {
+  ST_CHECK_ARG(out4_host != nullptr, "st_work_counters_read: NULL output");
+  unsigned long long* p = nullptr;
+  ST_TRY(st_work_counters_ptr(&p));
+  ST_HIP(hipMemcpy(out4_host, p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) ST_HIP(hipMemset(p, 0, 4 * sizeof(unsigned long long)));
+  return ST_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // x[r] = emb[token(s)] * sqrt(d) + pe[pos]   (model.py:126-133 Embeddings, :75-94 PositionalEncoding)
 // one wave per live row; also resets the *next* live counter (ping-pong, see st_decode_greedy).
@@ -83,11 +109,15 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ em
                                                     const int* __restrict__ idx, const int* __restrict__ n_dev,
                                                     int* __restrict__ n_next, int* __restrict__ n_amb,
                                                     const int32_t* __restrict__ ys, int T, int pos, int bos, int vocab,
-                                                    float* __restrict__ x) {
+                                                    float* __restrict__ x, unsigned long long* __restrict__ work) {
   const int n = *n_dev;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *n_next = 0;
     *n_amb = 0;
+    // executed work of this process (st_work_counters_read): token-steps and attended keys, exact live counts
+    atomicAdd(work + 0, (unsigned long long)n);
+    atomicAdd(work + 1, (unsigned long long)n * (unsigned long long)(pos + 1));
+    if (pos == 0) atomicAdd(work + 2, (unsigned long long)n);
   }
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
@@ -391,6 +421,8 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   }
   const int early = (options & ST_DEC_EARLY_EXIT) ? 1 : 0;
   const long kv_stride = (long)L * 2 * T * 256;
+  unsigned long long* work = nullptr;
+  ST_TRY(st_work_counters_ptr(&work));
 
   ST_HIP(hipMemsetAsync(out_ids, 0, (size_t)B * T * 4, st));  // PAD after an early exit
   if (top2gap) ST_HIP(hipMemsetAsync(top2gap, 0, (size_t)B * T * 4, st));
@@ -425,7 +457,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     const int* idx = ws.idx[cur];
     const int* n_dev = ws.cnt + cur;
     hipLaunchKernelGGL(embed_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, w->emb, w->pe, idx, n_dev,
-                       ws.cnt + (cur ^ 1), ws.cnt + 2, out_ids, T, pos, bos, w->vocab, ws.x);
+                       ws.cnt + (cur ^ 1), ws.cnt + 2, out_ids, T, pos, bos, w->vocab, ws.x, work);
     ST_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
       const StDecLayer& y = w->layer[l];

@@ -12,6 +12,49 @@ def headline(sent: str, note_token="*"):
     return note_token * 20 + sent + note_token * 20
 
 
+class VocabBytes:
+    """id_to_word as one UTF-8 byte string + offsets: the form st_format_attack_log reads"""
+
+    def __init__(self, id_to_word):
+        import numpy as np
+        enc = [w.encode("utf-8") for w in id_to_word]
+        self.bytes = b"".join(enc)
+        self.off = np.zeros(len(enc) + 1, np.int64)
+        np.cumsum([len(b) for b in enc], out=self.off[1:])
+        self.n = len(enc)
+
+
+def format_attack_block(vocab: VocabBytes, data, rec, first_index=0, eos=3, pad=0, unk=1, prefix=LOG_PREFIX):
+    """The log block of len(data) sentences as bytes (numpy uint8), formatted by the library's host function
+    st_format_attack_log (csrc/st_logfmt.cpp) from a CPU LeanRecord (attack.LeanRecord) and the origins of `data`
+    (an AttackSet covering exactly these sentences).  Same bytes as attack.write_attack_log through a LogWriter."""
+    import numpy as np
+    from . import _lib
+    L = _lib.lib()
+    S = len(data)
+    assert len(rec) == S
+    T = int(rec.init_ids.shape[1])
+    I = int(rec.changed.shape[1])
+    npy = lambda t, dt: None if t is None else np.ascontiguousarray(t.numpy(), dt)
+    n_iter, init, ch, rows = npy(rec.n_iter, np.int32), npy(rec.init_ids, np.int32), npy(rec.changed, np.uint8), npy(rec.rows, np.int32)
+    assert int(ch.sum()) == rows.shape[0], "changed flags and changed rows disagree"
+    like, unlike = npy(rec.like_ids, np.int32), npy(rec.unlike_ids, np.int32)
+    kp = 0 if like is None else like.shape[1]
+    kn = 0 if unlike is None else unlike.shape[1]
+    src = data.origin_r
+    src_tok, src_off = np.ascontiguousarray(src.tokens, np.int32), np.ascontiguousarray(src.off, np.int64)
+    ptr = lambda a: None if a is None else a.ctypes.data
+    args = (vocab.bytes, vocab.off.ctypes.data, vocab.n, eos, pad, unk, prefix.encode(), S, T, I, int(first_index),
+            ptr(src_tok), ptr(src_off), ptr(init), ptr(like), kp, ptr(unlike), kn, ptr(n_iter), ptr(ch), ptr(rows))
+    need = L.st_format_attack_log(*args, None, 0)
+    if need < 0:
+        raise ValueError("st_format_attack_log: bad argument")
+    out = np.empty(need, np.uint8)
+    got = L.st_format_attack_log(*args, out.ctypes.data, need)
+    assert got == need
+    return out
+
+
 class LogWriter:
     """print_and_log: message to stdout (optional) and to the log file with the reference's prefix."""
 
@@ -19,6 +62,20 @@ class LogWriter:
         self.f = open(path, "w") if path else None
         self.echo = echo
         self.lines = []
+
+    def write_block(self, block):
+        """a pre-formatted block of records (format_attack_block): bytes with prefix and newlines"""
+        raw = block.tobytes() if hasattr(block, "tobytes") else bytes(block)
+        if self.echo or not self.f:
+            msgs = [l[len(LOG_PREFIX):] for l in raw.decode("utf-8").split("\n")[:-1]]
+            if self.echo:
+                print("\n".join(msgs))
+            if not self.f:
+                self.lines.extend(msgs)
+        if self.f:
+            self.f.flush()
+            self.f.buffer.write(raw)
+            self.f.buffer.flush()
 
     def __call__(self, msg: str):
         if self.echo:

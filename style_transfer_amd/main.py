@@ -109,37 +109,47 @@ def dist_info():
     return rank, world, local
 
 
-def shard_range(n, rank, world):
-    """contiguous split of range(n) over ranks, sizes differing by at most one"""
-    base, rem = divmod(n, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+from .pipeline import gather_to_rank0, shard_range  # noqa: E402,F401  (shard_range is part of this module's API)
 
 
-def gather_results(res, world, backend_device):
-    """rank-ordered concatenation of the per-shard records on every rank (RCCL all_gather on device
-    tensors when backend_device is a GPU; gloo/CPU in the tests)."""
+def gather_dense_to_rank0(res, rank, world, device):
+    """--dance / trace runs keep the dense records (two iterations, small runs): every field incl. the dance loss and
+    scores and the final latents goes to rank 0 with the same exact-size send / recv as the lean records."""
     import torch
     import torch.distributed as dist
     from .attack import AttackResult
-    fields = ["n_iter", "init_ids", "iter_ids", "changed", "like_ids", "unlike_ids"]
+    fields = ["n_iter", "init_ids", "iter_ids", "changed", "like_ids", "unlike_ids", "final_latent"]
+    vals = {f: getattr(res, f) for f in fields}
+    if res.dance:
+        vals["dance_loss"], vals["dance_scores"] = res.dance["loss"], res.dance["scores"]
+    names = fields + ["dance_loss", "dance_scores"]
+    ten = {f: None if vals.get(f) is None else torch.from_numpy(np.ascontiguousarray(vals[f])).to(device) for f in names}
+    mine = torch.tensor([-1 if ten[f] is None else ten[f].shape[0] for f in names], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = torch.stack(sizes).cpu().tolist()
+    present = [all(sz[i] >= 0 for sz in sizes) for i in range(len(names))]
+    if rank != 0:
+        for i, f in enumerate(names):
+            if present[i] and ten[f].shape[0] > 0:
+                dist.send(ten[f], 0)
+        return None
     out = {}
-    for f in fields:
-        a = getattr(res, f)
-        if a is None:
+    for i, f in enumerate(names):
+        if not present[i]:
             out[f] = None
             continue
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(backend_device)
-        n = torch.tensor([t.shape[0]], device=backend_device)
-        ns = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(ns, n)
-        mx = int(max(x.item() for x in ns))
-        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=backend_device)
-        pad[: t.shape[0]] = t
-        parts = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad)
-        out[f] = np.concatenate([p[: int(k.item())].cpu().numpy() for p, k in zip(parts, ns)], 0)
-    return AttackResult(**out)
+        parts = [ten[f]]
+        for r in range(1, world):
+            buf = torch.empty((sizes[r][i],) + tuple(ten[f].shape[1:]), dtype=ten[f].dtype, device=device)
+            if sizes[r][i] > 0:
+                dist.recv(buf, r)
+            parts.append(buf)
+        out[f] = torch.cat(parts, 0).cpu().numpy()
+    full = AttackResult(*[out[f] for f in fields])
+    if res.dance:
+        full.dance = dict(res.dance, loss=out["dance_loss"], scores=out["dance_scores"])
+    return full
 
 
 def train_scorer_main(args, ae, vocab_size, data_path, save_path, device, rank, world, log):
@@ -192,6 +202,7 @@ def main(argv=None):
     import torch
     from . import weights as W
     from .attack import AttackConfig, AttackRunner, concat_results, empty_result, write_attack_log
+    from .pipeline import run_shard
     from .data import AttackSet, load_word_dict_info
     from .logfmt import LogWriter, headline
 
@@ -289,20 +300,47 @@ def main(argv=None):
     runner = AttackRunner(ae, scorer, cfg, device)
     runner.set_vocab(id_to_word)
     lo, hi = shard_range(len(data), rank, world)
-    parts = []
     t0 = time.perf_counter()
-    for b0 in range(lo, hi, args.attack_batch):
-        idx = list(range(b0, min(hi, b0 + args.attack_batch)))
-        parts.append(runner.run_batch(data.subset(idx), idx))
-    res = concat_results(parts) if parts else empty_result(cfg, data.n_pos, data.n_neg)   # more ranks than sentences
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
+    if args.dance:
+        # --dance prints per-iteration losses and score digests (siamese_contrastive.py:833-835): dense records, the
+        # Python writer (two iterations per sentence: small by construction)
+        parts = []
+        for b0 in range(lo, hi, args.attack_batch):
+            b1 = min(hi, b0 + args.attack_batch)
+            parts.append(runner.run_batch(data.span(b0, b1), list(range(b0, b1))))
+        res = concat_results(parts) if parts else empty_result(cfg, data.n_pos, data.n_neg)   # more ranks than sentences
+        if not parts:
+            res.dance = dict(loss=np.zeros((0, 2), np.float32), scores=np.zeros((0, 2, data.n_pos + data.n_neg), np.float32),
+                             n_pos=data.n_pos, not_nll=cfg.not_nll)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            res = gather_dense_to_rank0(res, rank, world, device)
+        if rank == 0:
+            write_attack_log(log, data, res, id_to_word, 0, dance=True)
+    else:
+        from .attack import LeanRecord
+        from .logfmt import VocabBytes, format_attack_block
+        vocab = VocabBytes(id_to_word) if rank == 0 else None
+        fmt = lambda b0, b1, rec: format_attack_block(vocab, data.span(b0, b1), rec, b0, args.id_eos, args.id_pad, args.id_unk)
+        kept = []
+        if world == 1:
+            # one GPU: records are downloaded, formatted and written batch by batch while the next batch computes
+            consume = lambda b0, b1, lean: log.write_block(fmt(b0, b1, lean.to("cpu", pinned=True)))
+        else:
+            consume = lambda b0, b1, lean: kept.append(lean)
+        run_shard(runner, data, lo, hi, args.attack_batch, consume)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            mine = LeanRecord.cat(kept) if kept else LeanRecord.empty(cfg, data.n_pos, data.n_neg, device)
+            full = gather_to_rank0(mine, rank, world, device)
+            if rank == 0:
+                log.write_block(fmt(0, len(data), full.cpu()))
     if world > 1:
         import torch.distributed as dist
-        res = gather_results(res, world, device)
         dist.barrier()
     if rank == 0:
-        write_attack_log(log, data, res, id_to_word, 0, dance=args.dance)
         log.close()
         print('Done')
         print('[st] %d sentences on %d GPU(s): %.2f s compute on rank 0 (%.1f sentences/s)' %

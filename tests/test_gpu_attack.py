@@ -129,11 +129,11 @@ def test_log_is_byte_identical_to_reference(env, gold_notnll, tmp_path):
     assert len(mb) == len(rb) == len(g["subset"])
     same = sum(1 for a, b in zip(mb, rb) if a == b)
     print("identical sentence blocks: %d of %d" % (same, len(rb)))
-    assert same >= len(rb) - 1
+    assert same == len(rb)
     S = len(g["subset"])
     a = extract_out(mine, 2, 2, limit=S)
     b = extract_out(ref, 2, 2, limit=S)
-    assert sum(1 for x, y in zip(a, b) if x == y) >= S - 1
+    assert a == b
 
 
 @pytest.mark.parametrize("tag,flags", [
@@ -400,3 +400,152 @@ def test_reverse_order_swaps_the_two_files(env, tmp_path):
     # the rate switch is by POSITION in the run (idx < 500, :740), not by file: with only six sentences every one of
     # them takes --pos_victim_lr, whatever --neg_victim_lr says
     assert blocks(["--pos_victim_lr=0.2", "--neg_victim_lr=0.9"], "c") == fwd
+
+
+def test_config4_one_million_sentences_through_the_product_pipeline(scorer_sd_torch, ae_sd_torch, ae_sd, scorer_sd, tmp_path):
+    """BASELINE config 4 at FULL size on one GPU: 2^20 distinct synthetic yelp-shaped sentences (21 M encoder inputs)
+    through the path the CLI uses — shard_range -> run_shard (prefetch / drain threads) -> compact records -> log text.
+    Every sentence must satisfy the reference's invariants (1 <= iterations <= 18; <= 7 changes; early stop only at the
+    7th change; a Change row differs from the text it replaces), and a random 64 of them must log EXACTLY the lines the
+    CPU oracle (numpy restatement of contrastive_attack_one, sentence by sentence) logs."""
+    import time
+    import st_oracle as O
+    from style_transfer_amd import weights as W
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet, load_word_counts
+    from style_transfer_amd.logfmt import LOG_PREFIX, VocabBytes, format_attack_block
+    from style_transfer_amd.pipeline import run_shard, shard_range
+    dev = torch.device("cuda", 0)
+    S, BATCH = 1 << 20, 32768
+    ae = W.AEWeights(ae_sd_torch, dev, gemm_format="f16x3")
+    scorer = W.ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev)
+    V = ae.vocab
+    counts = load_word_counts(os.path.join(GOLD, "yelp", "word_to_id.txt"), V)
+    t0 = time.perf_counter()
+    data = AttackSet.synthetic(S, V, "yelp", seed=2024, word_counts=counts)
+    t_gen = time.perf_counter() - t0
+    assert t_gen < 60, "the synthetic generator must not loop over sentences in Python"
+    cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False)
+    runner = AttackRunner(ae, scorer, cfg, dev)
+    id_to_word = [str(i) for i in range(V)]
+    vocab = VocabBytes(id_to_word)
+    rng = np.random.default_rng(99)
+    picks = np.sort(rng.choice(S, 64, replace=False))
+    got_lines = {}
+    stats = dict(n=0, iters=0, changes=0, early=0, bytes=0)
+    logf = open(tmp_path / "log", "wb")
+
+    def consume(b0, b1, lean):
+        rec = lean.to("cpu", pinned=True)
+        n_iter, ch, rows, init = rec.n_iter.numpy(), rec.changed.numpy(), rec.rows.numpy(), rec.init_ids.numpy()
+        nch = ch.sum(1).astype(np.int64)
+        assert n_iter.min() >= 1 and n_iter.max() <= 18 and nch.max() <= 7
+        assert (nch[n_iter < 18] == 7).all()                  # the only way to stop before iteration 18
+        assert not (ch.astype(bool) & (np.arange(18)[None, :] >= n_iter[:, None])).any()
+        assert (ch[n_iter < 18, :][np.arange(int((n_iter < 18).sum())), n_iter[n_iter < 18] - 1] == 1).all()   # ... AT the 7th change
+        # a Change row replaces a different row: the previous change of the same sentence, else the initial decode
+        start = np.concatenate([[0], np.cumsum(nch)])[:-1]
+        sent = np.repeat(np.arange(len(n_iter)), nch)
+        first = np.arange(rows.shape[0]) == start[sent]
+        prev = np.where(first[:, None], init[sent], rows[np.maximum(np.arange(rows.shape[0]) - 1, 0)])
+        assert (rows != prev).any(1).all()
+        block = format_attack_block(vocab, data.span(b0, b1), rec, b0)
+        logf.write(memoryview(block))
+        stats["n"] += b1 - b0; stats["iters"] += int(n_iter.sum()); stats["changes"] += int(nch.sum())
+        stats["early"] += int((n_iter < 18).sum()); stats["bytes"] += block.size
+        mine = [g for g in picks if b0 <= g < b1]
+        if mine:
+            text = block.tobytes().decode().split(LOG_PREFIX + "*" * 20 + "Sentence Pair.")[1:]
+            for g in mine:
+                blk = text[g - b0].split("\n")
+                assert blk[0] == "%d%s" % (g, "*" * 20)
+                got_lines[int(g)] = [l[len(LOG_PREFIX):] for l in blk[1:] if l]
+
+    lo, hi = shard_range(S, 0, 1)
+    t0 = time.perf_counter()
+    run_shard(runner, data, lo, hi, BATCH, consume)
+    dt = time.perf_counter() - t0
+    logf.close()
+    assert stats["n"] == S and os.path.getsize(tmp_path / "log") == stats["bytes"]
+    print("config 4: %d sentences end to end in %.1f s (%.0f sentences/s incl. packing, H2D, records D2H, %.0f MB of log "
+          "text); generator %.1f s; mean iterations %.2f, mean changes %.2f, %.1f %% stop early"
+          % (S, dt, S / dt, stats["bytes"] / 1e6, t_gen, stats["iters"] / S, stats["changes"] / S, 100.0 * stats["early"] / S))
+    # ---- oracle equality on the random 64 (global index >= 500 for all but a few: lr = neg_victim_lr = 0.2 either way) ----
+    ssd, psd = scorer_sd
+    exact = 0
+    bad = []
+    for g in picks:
+        g = int(g)
+        enc = lambda sents: O.encode_latent(ae_sd, O.pad_sequences(sents, V))
+        lines = []
+        O.attack_one(ae_sd, ssd, psd, enc([data.origin[g]]), enc(data.like[g]), enc(data.unlike[g]), 0.2, id_to_word, lines.append,
+                     not_nll=True)
+        mine = got_lines[g]
+        assert mine[0].startswith("Src: ") and mine[1].startswith("Rec: ")
+        assert mine[0] == "Src: " + " ".join(str(t) for t in data.origin[g])
+        if mine[2:] == lines:
+            exact += 1
+        else:
+            bad.append(g)
+    print("oracle equality on 64 random sentences of the million: %d exact %s" % (exact, bad))
+    # north-star bar: >= 99 % exact, and EVERY divergence traced: re-run the sentence with latents and top-2 gaps
+    # recorded and find the first iteration where GPU and oracle part
+    assert exact >= 63, bad
+    tcfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, want_trace=True, want_gap=True)
+    for g in bad:
+        res = AttackRunner(ae, scorer, tcfg, dev).run_batch(data.subset([g]), [g])
+        enc = lambda sents: O.encode_latent(ae_sd, O.pad_sequences(sents, V))
+        trace = []
+        x0 = enc([data.origin[g]])
+        O.attack_one(ae_sd, ssd, psd, x0, enc(data.like[g]), enc(data.unlike[g]), 0.2, id_to_word, lambda m: None, not_nll=True,
+                     trace=trace)
+        seqs = [(res.init_ids[0], x0, res.trace["init_latent"][0])]
+        seqs += [(res.trace["ids"][0, it], trace[it]["latent"], res.trace["latent"][0, it]) for it in range(len(trace))]
+        why = None
+        for k, (ids_gpu, lat_o, lat_g) in enumerate(seqs):
+            ids_o, gaps = O.greedy_decode(ae_sd, lat_o, 60, early_exit=True, want_gap=True)
+            e = text_end(ids_o[0])
+            dl = float(np.abs(lat_g - lat_o[0]).max())
+            if dl > 1e-4 * np.abs(lat_o).max():
+                # The latents part first (threshold 10x below the parity tolerance, to catch the ONSET): all decodes up to
+                # here agreed, so this is the scorer step, not the decoder.  Two f32 implementations of the scorer's
+                # backward pass legitimately differ where a hidden pre-activation is within rounding of a ReLU kink (the
+                # gradient of a piecewise-linear net jumps there) and where Adam's normalised early steps
+                # lr * m / (sqrt(v) + eps) turn a rounding-level difference on a small-gradient coordinate into a visible
+                # move (DESIGN.md section 2).  Recorded, not bounded: the budget is the >= 99 % exact-match bar above.
+                it = k - 1
+                co = int(np.abs(lat_g - lat_o[0]).argmax())
+                gmax = float(np.abs(trace[it]["grad"]).max())
+                gk = abs(float(trace[it]["grad"][0, co]))
+                assert it >= 0, "encoder latents differ"
+                why = "latent coordinate %d parts at iteration %d by %.2g: |grad| = %.2g of max %.2g (scorer step: ReLU kink or normalised early Adam step)" % (
+                    co, it, dl, gk, gmax)
+                break
+            if not np.array_equal(ids_gpu[:e + 1], ids_o[0][:e + 1]):
+                first = int(np.nonzero(ids_gpu[:e + 1] != ids_o[0][:e + 1])[0][0])
+                assert gaps[0, first] < NEAR_TIE, (g, k, first, float(gaps[0, first]), dl)
+                why = "decode %d, token %d: oracle top-2 gap %.2g at equal latents (argmax near-tie)" % (k, first, float(gaps[0, first]))
+                break
+        assert why is not None, ("sentence %d differs from the oracle in the batch run but not when re-run alone" % g)
+        print("divergence of sentence %d traced: %s" % (g, why))
+
+
+def test_bench_self_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must start its own two workers (one per GPU; here both
+    mapped onto this box's single GPU through the gloo rehearsal backend) and print ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ST_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2048", "--steps", "2",
+                          "--warmup", "1", "--no-side-runs"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["distinct_batches"] is True and j["config"]["sentences_per_step"] == 4096
+    assert j["value"] > 0 and j["whole_step"]["executed_token_steps"] > 0 and "cpu_baseline" not in j
+    assert abs(j["value"] - 4096 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]

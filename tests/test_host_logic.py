@@ -121,32 +121,65 @@ GATHER_WORKER = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
-from style_transfer_amd.main import gather_results, shard_range
-from style_transfer_amd.attack import AttackResult
+from style_transfer_amd.main import gather_dense_to_rank0
+from style_transfer_amd.pipeline import gather_to_rank0, shard_range
+from style_transfer_amd.attack import AttackConfig, AttackResult, LeanRecord, empty_result
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-from style_transfer_amd.attack import AttackConfig, empty_result
 I, T = 18, 59
 rng = np.random.default_rng(0)
+cfg = AttackConfig(log_decodes=True)
 for S in (11, 1):          # S = 1: rank 1 holds an empty shard (more ranks than sentences)
-    full = AttackResult(rng.integers(0, 19, S).astype(np.int32), rng.integers(0, 9000, (S, T)).astype(np.int32),
-                        rng.integers(0, 9000, (S, I, T)).astype(np.int32), rng.integers(0, 2, (S, I)).astype(np.uint8),
-                        rng.integers(0, 9000, (S, 10, T)).astype(np.int32), None)
+    n_iter = rng.integers(1, 19, S).astype(np.int32)
+    changed = (rng.integers(0, 3, (S, I)) == 0).astype(np.uint8) * (np.arange(I)[None, :] < n_iter[:, None])
+    rows = rng.integers(0, 9000, (int(changed.sum()), T)).astype(np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    full = LeanRecord(t(n_iter), t(rng.integers(0, 9000, (S, T)).astype(np.int32)), t(changed.astype(np.uint8)), t(rows),
+                      t(rng.integers(0, 9000, (S, 10, T)).astype(np.int32)), None, t(rng.standard_normal((S, 256)).astype(np.float32)))
     lo, hi = shard_range(S, rank, world)
-    mine = AttackResult(full.n_iter[lo:hi], full.init_ids[lo:hi], full.iter_ids[lo:hi], full.changed[lo:hi], full.like_ids[lo:hi], None)
+    r0, r1 = int(changed[:lo].sum()), int(changed[:hi].sum())
+    mine = LeanRecord(full.n_iter[lo:hi], full.init_ids[lo:hi], full.changed[lo:hi], full.rows[r0:r1], full.like_ids[lo:hi], None,
+                      full.final_latent[lo:hi])
     if lo == hi:
-        mine = empty_result(AttackConfig(log_decodes=True), 10, 0)
-    got = gather_results(mine, world, torch.device("cpu"))
-    for f in ("n_iter", "init_ids", "iter_ids", "changed", "like_ids"):
-        assert np.array_equal(getattr(got, f), getattr(full, f)), f
-    assert got.unlike_ids is None
+        mine = LeanRecord.empty(AttackConfig(log_decodes=True), 10, 0, want_latent=True)
+    got = gather_to_rank0(mine, rank, world, "cpu")
+    if rank == 0:
+        for f in ("n_iter", "init_ids", "changed", "rows", "like_ids", "final_latent"):
+            assert torch.equal(getattr(got, f), getattr(full, f)), f
+        assert got.unlike_ids is None
+        dense = got.expand()                      # dense table from the changed rows
+        k = 0
+        for s in range(S):
+            cur = full.init_ids[s].numpy()
+            for it in range(I):
+                if changed[s, it]:
+                    cur = rows[k]; k += 1
+                want = cur if it < n_iter[s] else np.zeros(T, np.int32)
+                assert np.array_equal(dense.iter_ids[s, it], want), (s, it)
+    else:
+        assert got is None
+    # --dance keeps the dense records, with the loss / score tables and the final latents (ADVICE r1: these were dropped)
+    dfull = AttackResult(n_iter, full.init_ids.numpy(), rng.integers(0, 9000, (S, 2, T)).astype(np.int32),
+                         np.zeros((S, 2), np.uint8), full.like_ids.numpy(), None, full.final_latent.numpy())
+    dfull.dance = dict(loss=rng.standard_normal((S, 2)).astype(np.float32), scores=rng.standard_normal((S, 2, 20)).astype(np.float32),
+                       n_pos=10, not_nll=True)
+    dm = AttackResult(dfull.n_iter[lo:hi], dfull.init_ids[lo:hi], dfull.iter_ids[lo:hi], dfull.changed[lo:hi], dfull.like_ids[lo:hi],
+                      None, dfull.final_latent[lo:hi])
+    dm.dance = dict(dfull.dance, loss=dfull.dance["loss"][lo:hi], scores=dfull.dance["scores"][lo:hi])
+    dg = gather_dense_to_rank0(dm, rank, world, "cpu")
+    if rank == 0:
+        for f in ("n_iter", "init_ids", "iter_ids", "changed", "like_ids", "final_latent"):
+            assert np.array_equal(getattr(dg, f), getattr(dfull, f)), f
+        assert np.array_equal(dg.dance["loss"], dfull.dance["loss"]) and np.array_equal(dg.dance["scores"], dfull.dance["scores"])
+        assert dg.dance["n_pos"] == 10 and dg.dance["not_nll"] is True
 dist.destroy_process_group()
 open(os.path.join(%(out)r, "ok%%d" %% rank), "w").write("ok")
 """
 
 
 def test_two_rank_gather_reassembles_global_order(tmp_path):
-    """N > 1 path: contiguous shards, all_gather of ragged per-shard records, global order restored (gloo)."""
+    """N > 1 path: contiguous shards, the compact records (changed rows only) sent to rank 0 with exact sizes, global
+    order restored, dense table rebuilt; --dance's dense records incl. loss / scores / latents (gloo)."""
     import socket
     with socket.socket() as so:          # a free rendezvous port (a fixed one can collide with another run)
         so.bind(("127.0.0.1", 0))
@@ -307,3 +340,78 @@ def test_epoch_order_is_the_reference_shuffle():
     batches = epoch_order(1000, 128)
     assert len(batches) == 7 and all(len(b) == 128 for b in batches)
     assert ["r%d" % i for b in batches for i in b] == items[:896]
+
+
+def test_ragged_sets_behave_like_the_lists_they_replace():
+    from style_transfer_amd.data import AttackSet, Ragged, pack_sentences
+    sents = [[5, 6, 7], [], [9], [4, 8]]
+    r = Ragged.from_lists(sents)
+    assert len(r) == 4 and list(r) == sents and r[-1] == [4, 8] and r.lens.tolist() == [3, 0, 1, 2]
+    assert list(r.take([3, 0, 3])) == [[4, 8], [5, 6, 7], [4, 8]] and list(r.span(1, 3)) == [[], [9]]
+    assert list(Ragged.concat([r.span(0, 1), r.span(2, 4)])) == [[5, 6, 7], [9], [4, 8]]
+    d = AttackSet([[4, 5], [6]], [[[7], [8, 9]], [[10], []]], [[[11]], [[12, 13]]])
+    assert (len(d), d.n_pos, d.n_neg) == (2, 2, 1) and d.like[1] == [[10], []] and d.unlike[0] == [[11]]
+    assert list(d.all_sentences()) == [[4, 5], [6], [7], [8, 9], [10], [], [11], [12, 13]]
+    sub = d.subset([1, 1, 0])
+    assert sub.origin[0] == [6] and sub.like[2] == [[7], [8, 9]] and sub.unlike[1] == [[12, 13]]
+    sp = d.span(1, 2)
+    assert len(sp) == 1 and sp.origin[0] == [6] and sp.like[0] == [[10], []]
+    # the vectorised synthetic generator: shapes of SURVEY 8d, a million-scale call must not loop in Python
+    syn = AttackSet.synthetic(5000, 9339, "yelp", seed=3)
+    ol, rl = syn.origin_r.lens, syn.like_r.lens
+    assert ol.min() >= 6 and ol.max() <= 15 and abs(ol.mean() - 10.3) < 0.3 and rl.min() == 1 and rl.max() == 16
+    assert syn.origin_r.tokens.min() >= 4 and syn.origin_r.tokens.max() < 9339 and len(syn.unlike_r) == 50000
+    tok, pos, off, mx = pack_sentences(syn.all_sentences())
+    assert off[-1] == tok.size and mx == 16 and pos.max() == 15
+    am = AttackSet.synthetic(100, 19724, "amazon", seed=3)
+    assert am.origin_r.lens.min() >= 8 and am.like_r.lens.min() >= 8 and am.like_r.lens.max() == 31
+
+
+def test_log_formatter_matches_the_python_writer(id_to_word):
+    """st_format_attack_log (host C function; compact records) writes the same bytes as the per-sentence Python
+    writer on the dense records: Src / Rec / Sim / Ref lines, Change numbering, repeated iteration texts, ids >= V
+    -> <UNK>, texts cut at EOS / PAD, empty texts, sentences that stop early."""
+    import torch
+    from style_transfer_amd.attack import AttackConfig, LeanRecord, write_attack_log
+    from style_transfer_amd.data import AttackSet
+    from style_transfer_amd.logfmt import LOG_PREFIX, LogWriter, VocabBytes, format_attack_block
+    rng = np.random.default_rng(11)
+    S, I, T, V = 40, 18, 59, len(id_to_word)
+
+    def ids_row():
+        n = int(rng.integers(0, 14))
+        row = rng.integers(4, V + 50, T).astype(np.int32)      # some ids beyond the vocabulary
+        row[n] = 3 if rng.random() < 0.7 else 0
+        return row
+    n_iter = rng.integers(1, I + 1, S).astype(np.int32)
+    changed = ((rng.random((S, I)) < 0.35) & (np.arange(I)[None, :] < n_iter[:, None])).astype(np.uint8)
+    rows = np.stack([ids_row() for _ in range(int(changed.sum()))]) if changed.sum() else np.zeros((0, T), np.int32)
+    init = np.stack([ids_row() for _ in range(S)])
+    data = AttackSet.synthetic(S, V, "yelp", n_pos=3, n_neg=2, seed=5)
+    for with_refs in (False, True):
+        like = np.stack([ids_row() for _ in range(S * 3)]).reshape(S, 3, T) if with_refs else None
+        unlike = np.stack([ids_row() for _ in range(S * 2)]).reshape(S, 2, T) if with_refs else None
+        t = lambda a: None if a is None else torch.from_numpy(a)
+        rec = LeanRecord(t(n_iter), t(init), t(changed), t(rows), t(like), t(unlike))
+        block = format_attack_block(VocabBytes(id_to_word), data, rec, first_index=500)
+        w = LogWriter(None, echo=False)
+        write_attack_log(w, data, rec.expand(), id_to_word, first_index=500)
+        want = "".join(LOG_PREFIX + m + "\n" for m in w.lines)
+        assert block.tobytes().decode("utf-8") == want
+        w2 = LogWriter(None, echo=False)
+        w2.write_block(block)
+        assert w2.lines == w.lines
+
+
+def test_bench_self_launch_control_flow_without_a_gpu():
+    """`python bench.py --gpus 2 --dry-run`, no launcher: two worker processes, gloo rendezvous on 127.0.0.1, barrier,
+    max-over-ranks timing, exactly one JSON line (rank 0).  The same code path starts the real N-GPU run."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["dry_run"] is True and j["ms_per_step"] >= 20.0   # the slower rank's time
