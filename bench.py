@@ -301,7 +301,9 @@ def main(argv=None):
         from style_transfer_amd.logfmt import LogWriter, VocabBytes, format_attack_block
         from style_transfer_amd.pipeline import run_shard
         from style_transfer_amd.data import Ragged
-        id_to_word, _ = load_word_dict_info(os.path.join(GOLD, a.shape, "word_to_id.txt"), 5)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # (the loader prints the reference's banner line)
+            id_to_word, _ = load_word_dict_info(os.path.join(GOLD, a.shape, "word_to_id.txt"), 5)
         vocab = VocabBytes(id_to_word)
         n_e2e = min(len(sets), 4) if not a.same_batch else 1
         big = AttackSet(Ragged.concat([s.origin_r for s in sets[:n_e2e]]), Ragged.concat([s.like_r for s in sets[:n_e2e]]),
