@@ -31,8 +31,36 @@ def split(x, rnd):
     return h, rnd((x - h).astype(F32))
 
 
+def round_mantissa(x, bits):
+    """round f32 to `bits` explicit mantissa bits (f32 exponent range kept): models an 8-bit residual"""
+    u = np.ascontiguousarray(x, F32).view(np.uint32).astype(np.uint64)
+    sh = 23 - bits
+    r = ((u + (1 << (sh - 1)) - 1 + ((u >> sh) & 1)) >> sh) << sh
+    return r.astype(np.uint32).view(F32).reshape(np.shape(x))
+
+
 def make_linear(mode, sd):
     cache = {}
+    if mode.startswith("kv:"):
+        # exact f32 products everywhere; only what is STORED in the decoder's K/V cache is rounded:
+        # kv:f16 = f16 value; kv:bf16; kv:f16+m3 = f16 value + residual with a 3-bit mantissa (3 bytes per element)
+        inner = make_linear("f32", sd)
+        kind = mode[3:]
+
+        def lin_kv(x, sd_, prefix):
+            y = inner(x, sd_, prefix)
+            if prefix.startswith("decoder.") and (prefix.endswith("self_attn.linears.1") or prefix.endswith("self_attn.linears.2")):
+                if kind == "f16":
+                    y = to_f16(y)
+                elif kind == "bf16":
+                    y = to_bf16(y)
+                elif kind.startswith("f16+m"):
+                    h = to_f16(y)
+                    y = (h + round_mantissa((y - h).astype(F32), int(kind[5:]))).astype(F32)
+                else:
+                    raise ValueError(mode)
+            return y
+        return lin_kv
 
     def lin(x, sd_, prefix):
         w = sd_[prefix + ".weight"]

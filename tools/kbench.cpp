@@ -155,8 +155,35 @@ int main(int argc, char** argv) {
     a.fmt = g_fmt;
     a.att = att; a.n_host = n; a.wo = wo_p; a.bo = bias; a.x = x; a.ln_a = ln_a; a.ln_b = ln_b; a.w1 = w1_p; a.b1 = bias;
     a.w2 = w2_p; a.b2 = bias; a.d_ff = DFF;
-    t = timeit([&] { launch_layer_tail(a, n, st); });
+    t = timeit([&] { launch_layer_tail64(a, n, st); });
     printf("layer tail n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + 2 * DFF) / t / 1e12);
+    {
+      // A/B: the 32-row / 4-wave form (two workgroups per CU), interleaved rounds, and a bitwise comparison of the outputs
+      double t64 = 0, t32 = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        t64 += timeit([&] { launch_layer_tail64(a, n, st); }, 5);
+        t32 += timeit([&] { launch_layer_tail32(a, n, st); }, 5);
+      }
+      printf("layer tail A/B n=%d: 64-row x 8 waves %8.1f us   32-row x 4 waves %8.1f us  (%.3f)\n", n, t64 / 3 * 1e6, t32 / 3 * 1e6, t32 / t64);
+      std::vector<float> x0((size_t)n * 256), y64(x0.size()), y32(x0.size());
+      float* xs = dev_rand((size_t)n * 256, 1.0f, 1);
+      CK(hipMemcpy(x0.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      OFArgs b = a;
+      b.x = xs;
+      launch_layer_tail64(b, n, st);
+      CK(hipMemcpy(y64.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(xs, x0.data(), x0.size() * 4, hipMemcpyHostToDevice));
+      launch_layer_tail32(b, n, st);
+      CK(hipMemcpy(y32.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      size_t diff = 0;
+      double mx = 0;
+      for (size_t i = 0; i < x0.size(); ++i) {
+        if (memcmp(&y64[i], &y32[i], 4)) ++diff;
+        const double d = fabs((double)y64[i] - (double)y32[i]);
+        if (d > mx) mx = d;
+      }
+      printf("  outputs: %zu of %zu elements differ bitwise, max |diff| %.3g, sample y64 %g y32 %g\n", diff, x0.size(), mx, y64[12345], y32[12345]);
+    }
 #ifdef ST_TAIL_STAMPS
     unsigned long long hs[64];
     CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_tail_stamps), sizeof(hs)));
