@@ -312,6 +312,44 @@ int st_adam_step(float* params, const float* grads, float* adam_m, float* adam_v
                  float beta2, float eps, int step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (8b) One optimisation step of the AUTOENCODER under the in-batch constraint: loss and gradients of the loop body of
+ * train_ae_model_constraint (siamese_contrastive.py:1028-1072; SURVEY §8f rank 3, second half) — EncoderDecoder.forward
+ * in TRAIN mode (model.py:229-250), LabelSmoothing / ntokens (model.py:389-411, :1040-1041), the B x B similarity loss
+ * over the `like` views plus a second pass of the origins (:1049-1071), (bata * constraint + rec).backward() (:1072).
+ * The optimizer (NoamOpt + Adam(betas 0.9 / 0.98, eps 1e-9), :1009-1010, model.py:355-381) is st_adam_step on the flat
+ * vectors with lr = the Noam rate, so a data-parallel caller can all-reduce `grads_flat` in between.
+ *   p / g        parameters and gradients: host structs of DEVICE pointers, plain row-major nn.Linear tensors; g points
+ *                into grads_flat [n_params] (zeroed here; tensors that receive no gradient — the source attention's
+ *                query / key projections and its LayerNorm, whose softmax runs over ONE memory position — stay zero)
+ *   encoder input, length-packed: (1 + views) * B sentences in the order  origins | view 0 (B sentences) | ... |
+ *                origins again (the reference's ori_latent_cp pass); enc_tokens / enc_pos [n_enc_rows], enc_off [n_enc_sent + 1]
+ *   decoder input, length-packed teacher forcing of the B origins: rows BOS, t0, .. (dec_tokens), targets t0, .., EOS
+ *                (dec_targets), positions dec_pos, dec_off [B + 1]; sentences <= 64 rows
+ *   drop_p, seed  Dropout probability (reference: 0.1) and the seed of the counter-hash keep decisions
+ *   losses_out [2] (device): reconstruction loss (sum / ntokens), constraint loss (before * bata)
+ * Requires B % 32 == 0 (similarity block backward).                                                              */
+typedef struct StAeLayer {
+  const float *ln0_a, *ln0_b;                          /* sublayer[0].norm                                  */
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;  /* self_attn.linears[0..3]                           */
+  const float *xv_w, *xv_b, *xo_w, *xo_b;              /* decoder: src_attn.linears[2], [3]                 */
+  const float *ln2_a, *ln2_b;                          /* norm before the feed-forward (encoder: sublayer[1], decoder: sublayer[2]) */
+  const float *w1, *b1, *w2, *b2;                      /* feed_forward                                      */
+} StAeLayer;
+typedef struct StAeParams {
+  int32_t d_model, n_heads, d_ff, n_layers, vocab, pe_rows;
+  const float *emb, *pe;                               /* shared src / tgt embedding [V,256]; positional table */
+  const float *enc_norm_a, *enc_norm_b, *dec_norm_a, *dec_norm_b;
+  const float *gen_w, *gen_b;                          /* generator.proj [V,256], [V]                        */
+  StAeLayer enc[ST_MAX_LAYERS], dec[ST_MAX_LAYERS];
+} StAeParams;
+size_t st_ae_train_workspace_bytes(const StAeParams* p, int n_enc_rows, int n_enc_sent, int n_dec_rows, int B);
+int st_ae_train_step(const StAeParams* p, const StAeParams* g, float* grads_flat, int64_t n_params,
+                     const int32_t* enc_tokens, const int32_t* enc_pos, const int32_t* enc_off, int n_enc_rows,
+                     int n_enc_sent, const int32_t* dec_tokens, const int32_t* dec_pos, const int32_t* dec_targets,
+                     const int32_t* dec_off, int n_dec_rows, int B, float bata, float tau, float smoothing, float drop_p,
+                     uint64_t seed, float* losses_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (9) HOST function (no GPU work, all pointers are host pointers): the per-sentence block of the log that
  * attack_contrastive / contrastive_attack_one print (siamese_contrastive.py:702-732, :789, :825-836) with
  * id2text_sentence (data.py:43-52), from the compact per-sentence records:

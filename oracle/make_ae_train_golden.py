@@ -2,8 +2,8 @@
 
 Runs the UNMODIFIED reference function train_ae_model_constraint (siamese_contrastive.py:1000-1088) — its own data
 loaders (create_ae_data_loader :950-997, AttackDataLoader data.py:298-505, shuffle seed 234), EncoderDecoder.forward,
-batch_forward, LabelSmoothing, NoamOpt + Adam — for one epoch of TWO batches of 12 records on the surrogate AE
-checkpoint.  The records are the first 12 of each yelp test JSON (origin + sim0..9), written to a temporary data
+batch_forward, LabelSmoothing, NoamOpt + Adam — for one epoch of TWO batches of 32 records on the surrogate AE
+checkpoint.  The records are the first 32 of each yelp test JSON (origin + sim0..9), written to a temporary data
 directory under the file names the function reads (ae_train_constraint{0,1}.json).  Nothing is restated: NoamOpt.step
 and Accumulator.inc are wrapped only to RECORD gradients, parameters and the two losses of every step.
 
@@ -30,8 +30,8 @@ import ref_harness  # noqa: E402
 from make_goldens import GOLD, load_ae  # noqa: E402
 
 STRIDE = 37
-PER_FILE = 12
-BATCH = 12
+PER_FILE = 32
+BATCH = 32
 
 
 def main():
@@ -104,7 +104,7 @@ def main():
             random.seed(234)
             random.shuffle(order)
             out = {k: np.stack(v) for k, v in rec.items()}
-            out["order"] = np.asarray(order, np.int32)       # record k of the run = record order[k] of [file0[:12] + file1[:12]]
+            out["order"] = np.asarray(order, np.int32)       # record k of the run = record order[k] of [file0[:32] + file1[:32]]
             out["names"] = np.array(names)
             out["small_names"] = np.array(small)
             out["sizes"] = np.array([named[n].numel() for n in names], np.int64)
@@ -112,7 +112,7 @@ def main():
             out["bata"], out["tau"] = np.float32(args.bata), np.float32(args.tau)
             if drop > 0:
                 # per step: the keep-masks of every nn.Dropout call in call order, bit-packed and concatenated; sizes beside
-                for s, ms in enumerate(mask_steps):
+                for s, ms in enumerate(mask_steps[:1]):      # (step 0 only: 5 MB of bits per step)
                     out["mask_sizes_%d" % s] = np.array([m.size for m in ms], np.int64)
                     out["masks_%d" % s] = np.concatenate(ms)
             np.savez_compressed(os.path.join(GOLD, "ae_train_%s.npz" % tag), **out)

@@ -54,6 +54,20 @@ class StEncoderWeights(C.Structure):
                 ("layer", StEncLayer * ST_MAX_LAYERS)]
 
 
+class StAeLayer(C.Structure):
+    _fields_ = [(n, fp) for n in (
+        "ln0_a", "ln0_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "xv_w", "xv_b", "xo_w", "xo_b",
+        "ln2_a", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
+class StAeParams(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
+                ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
+                ("emb", fp), ("pe", fp), ("enc_norm_a", fp), ("enc_norm_b", fp), ("dec_norm_a", fp), ("dec_norm_b", fp),
+                ("gen_w", fp), ("gen_b", fp),
+                ("enc", StAeLayer * ST_MAX_LAYERS), ("dec", StAeLayer * ST_MAX_LAYERS)]
+
+
 class StClassifierWeights(C.Structure):
     _fields_ = [(n, fp) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
 
@@ -86,6 +100,10 @@ EXPORTS = {
     "st_scorer_train_step": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, fp, C.c_uint64,
                                        fp, fp, fp, fp, C.c_size_t, fp]),
     "st_adam_step": (C.c_int, [fp, fp, fp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp]),
+    "st_ae_train_workspace_bytes": (C.c_size_t, [C.POINTER(StAeParams), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "st_ae_train_step": (C.c_int, [C.POINTER(StAeParams), C.POINTER(StAeParams), fp, C.c_int64, fp, fp, fp, C.c_int, C.c_int,
+                                   fp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64,
+                                   fp, fp, C.c_size_t, fp]),
     "st_format_attack_log": (C.c_longlong, [C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                             C.c_int, C.c_longlong, fp, fp, fp, fp, C.c_int, fp, C.c_int, fp, fp, fp, fp,
                                             C.c_longlong]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libst_kernels.so")
-SOURCES = ["st_decode.hip", "st_scorer.hip", "st_accept.hip", "st_simloss.hip", "st_encode.hip", "st_fgim.hip", "st_train.hip", "st_logfmt.cpp"]
+SOURCES = ["st_decode.hip", "st_scorer.hip", "st_accept.hip", "st_simloss.hip", "st_encode.hip", "st_fgim.hip", "st_train.hip", "st_aetrain.hip", "st_logfmt.cpp"]
 
 
 def sources():

@@ -1,0 +1,777 @@
+// One optimisation step of the autoencoder's constraint training (second half): loss and
+// gradients of the loop body of train_ae_model_constraint (/root/reference/method/yelp/siamese_contrastive.py:1028-1072):
+//
+//   ori_latent, out = ae_model.forward(ori)                     model.py:229-250, TRAIN mode (dropout 0.1 everywhere)
+//   loss_rec = LabelSmoothing(out, tgt_y) / ntokens             model.py:389-411, :1040-1041
+//   like_latent = 10 `like` views + a second pass of the origins (:1049-1056)
+//   constraint = mean over the 11 views of NLL(log_softmax(cos(ori_i, like_j) / tau), i)     :1060-1071
+//   (bata * constraint + loss_rec).backward()                   :1072
+//
+// MI355X formulation: everything is LENGTH-PACKED (no padding rows): the 12 encoder passes of the reference (origins,
+// 10 views, origins again; each B separate batch-1..B calls) are ONE packed batch of 12 B sentences, so every encoder
+// weight gradient is one contraction over all rows; the reference's teacher-forced decodes of the views (model.py:248-249,
+// outputs unused) are not computed.  The decoder's source attention sees ONE memory position (the latent), so its softmax
+// is 1: the query / key projections and sublayer[1].norm receive exactly zero gradient.  f32 throughout; matrix products
+// on v_mfma_f32_32x32x2_f32 (64x64 LDS tiles, arbitrary operand strides: one kernel serves Y = X W^T, dX = dY W and
+// dW = dY^T X).  The B x B similarity blocks are st_simloss_fwd / st_simloss_bwd.  Dropout keep decisions are a counter
+// hash of (seed, site, sentence, position, feature): regenerated in the backward pass, never stored, and reproducible
+// on the host (tests replay them through the CPU restatement).
+#include <math.h>
+
+#include "st_common.h"
+
+#ifndef ST_TRY
+#define ST_TRY(x)            \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != ST_OK) return rc_; \
+  } while (0)
+#endif
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// dropout: keep(seed, site, idx) with P(keep) = 1 - p
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t ae_mix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+struct Drop {
+  uint64_t seed;
+  float p, scale;  // scale = 1 / (1 - p); p == 0: identity
+  uint32_t site;
+};
+__device__ __forceinline__ float drop_factor(const Drop& d, uint64_t idx) {
+  if (d.p <= 0.0f) return 1.0f;
+  const uint64_t h = ae_mix(ae_mix(d.seed ^ ((uint64_t)d.site << 40)) ^ idx);
+  const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+  return u >= d.p ? d.scale : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[i,j] (+)= bias[j] + sum_r A(i,r) B(r,j),  A(i,r) = A[i*sai + r*sar],  B(r,j) = B[r*sbr + j*sbj]
+// ------------------------------------------------------------------------------------------------
+struct GArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, R;
+  long sai, sar, sbr, sbj;
+  int ldc, accumulate;
+};
+#define AG_LD 68
+__global__ __launch_bounds__(256) void ae_gemm_kernel(GArgs a) {
+  __shared__ float As[16][AG_LD], Bs[16][AG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const bool a_r_fast = a.sar == 1, b_r_fast = a.sbr == 1;
+  float ra[4], rb[4];
+  auto fetch = [&](int rc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int ar = a_r_fast ? (e & 15) : (e >> 6), ai = a_r_fast ? (e >> 4) : (e & 63);
+      const int br = b_r_fast ? (e & 15) : (e >> 6), bj = b_r_fast ? (e >> 4) : (e & 63);
+      ra[q] = (i0 + ai < a.M && rc + ar < a.R) ? a.A[(long)(i0 + ai) * a.sai + (long)(rc + ar) * a.sar] : 0.0f;
+      rb[q] = (j0 + bj < a.N && rc + br < a.R) ? a.B[(long)(rc + br) * a.sbr + (long)(j0 + bj) * a.sbj] : 0.0f;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32, l31 = lane & 31, half = lane >> 5;
+  if (a.R > 0) fetch(0);
+  for (int rc = 0; rc < a.R; rc += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int ar = a_r_fast ? (e & 15) : (e >> 6), ai = a_r_fast ? (e >> 4) : (e & 63);
+      const int br = b_r_fast ? (e & 15) : (e >> 6), bj = b_r_fast ? (e >> 4) : (e & 63);
+      As[ar][ai] = ra[q];
+      Bs[br][bj] = rb[q];
+    }
+    __syncthreads();
+    if (rc + 16 < a.R) fetch(rc + 16);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) acc = mfma32(As[2 * kk + half][wi + l31], Bs[2 * kk + half][wj + l31], acc);
+  }
+  const int j = j0 + wj + l31;
+  const float bj = (a.bias && j < a.N) ? a.bias[j] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wi + mfma32_row(r, lane);
+    if (i < a.M && j < a.N) {
+      float* c = a.C + (long)i * a.ldc + j;
+      *c = (a.accumulate ? *c : 0.0f) + acc[r] + bj;
+    }
+  }
+}
+
+// column sums: out[c] = sum_rows X[row][c]   (one block per 64 columns; fixed order)
+__global__ __launch_bounds__(256) void ae_colsum_kernel(const float* __restrict__ X, int rows, int N, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rg = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < N)
+    for (int r = rg; r < rows; r += 4) s += X[(long)r * N + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < N) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// x = dropout(emb[token] * sqrt(d) + pe[pos])      (model.py:126-133, :75-94)   wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ae_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
+                                                       const int32_t* __restrict__ tok, const int32_t* __restrict__ pos,
+                                                       const int32_t* __restrict__ row_sent, int n, int vocab, Drop dr,
+                                                       float* __restrict__ x) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int t = min(max(tok[r], 0), vocab - 1);
+  const f32x4 e = *(const f32x4*)(emb + (size_t)t * 256 + lane * 4);
+  const f32x4 p = *(const f32x4*)(pe + (size_t)pos[r] * 256 + lane * 4);
+  f32x4 v = e * 16.0f + p;
+  const uint64_t base = ((uint64_t)row_sent[r] * 64 + pos[r]) * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] *= drop_factor(dr, base + j);
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = v;
+}
+// d emb[token] += sqrt(d) * dropout'(dx)
+__global__ __launch_bounds__(256) void ae_embed_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ tok,
+                                                           const int32_t* __restrict__ pos, const int32_t* __restrict__ row_sent,
+                                                           int n, int vocab, Drop dr, float* __restrict__ demb) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int t = min(max(tok[r], 0), vocab - 1);
+  const f32x4 g = *(const f32x4*)(dx + (size_t)r * 256 + lane * 4);
+  const uint64_t base = ((uint64_t)row_sent[r] * 64 + pos[r]) * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) atomicAdd(demb + (size_t)t * 256 + lane * 4 + j, 16.0f * g[j] * drop_factor(dr, base + j));
+}
+
+// ------------------------------------------------------------------------------------------------
+// the reference's LayerNorm (model.py:97-108): a (x - mean) / (std_unbiased + 1e-6) + b     wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ae_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                        const float* __restrict__ b, int n, float* __restrict__ y) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const f32x4 v = *(const f32x4*)(x + (size_t)r * 256 + lane * 4);
+  const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+  const f32x4 c = v - mu;
+  const float s = sqrtf(wave_sum(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) * (1.0f / 255.0f));
+  const float inv = 1.0f / (s + 1e-6f);
+  const f32x4 ga = *(const f32x4*)(a + lane * 4), gb = *(const f32x4*)(b + lane * 4);
+  *(f32x4*)(y + (size_t)r * 256 + lane * 4) = ga * (c * inv) + gb;
+}
+// dx (+)= LN'(dy); da += sum dy * xhat, db += sum dy  (f32 atomics into [256])
+__global__ __launch_bounds__(256) void ae_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ a, int n, float* __restrict__ dx,
+                                                        int accumulate, float* __restrict__ da, float* __restrict__ db) {
+  __shared__ float sa[4][256], sb[4][256];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+  const f32x4 ga = *(const f32x4*)(a + lane * 4);
+  for (int r = blockIdx.x * 4 + w; r < n; r += gridDim.x * 4) {
+    const f32x4 v = *(const f32x4*)(x + (size_t)r * 256 + lane * 4);
+    const f32x4 g = *(const f32x4*)(dy + (size_t)r * 256 + lane * 4);
+    const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+    const f32x4 c = v - mu;
+    const float s = sqrtf(wave_sum(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) * (1.0f / 255.0f));
+    const float d = s + 1e-6f, inv = 1.0f / d;
+    pa += g * (c * inv);
+    pb += g;
+    const f32x4 gy = g * ga;
+    const float dot = wave_sum(gy.x * c.x + gy.y * c.y + gy.z * c.z + gy.w * c.w);
+    // d/dxc of xc / (s + eps): gy / d - (gy . xc) / d^2 * xc / (255 s)
+    const float k = s > 0.0f ? dot * inv * inv / (255.0f * s) : 0.0f;
+    f32x4 dxc = gy * inv - k * c;
+    const float m = wave_sum(dxc.x + dxc.y + dxc.z + dxc.w) * (1.0f / 256.0f);
+    dxc = dxc - m;
+    float* o = dx + (size_t)r * 256 + lane * 4;
+    if (accumulate) dxc += *(const f32x4*)o;
+    *(f32x4*)o = dxc;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sa[w][lane * 4 + j] = pa[j];
+    sb[w][lane * 4 + j] = pb[j];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  atomicAdd(da + c, (sa[0][c] + sa[1][c]) + (sa[2][c] + sa[3][c]));
+  atomicAdd(db + c, (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise pieces
+// ------------------------------------------------------------------------------------------------
+// out = x + dropout(y)     (SublayerConnection, model.py:121-123); width 256
+__global__ __launch_bounds__(256) void ae_resid_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const int32_t* __restrict__ pos, const int32_t* __restrict__ row_sent,
+                                                       int n, Drop dr, float* __restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 v = *(const f32x4*)(y + (size_t)r * 256 + lane * 4);
+  const uint64_t base = ((uint64_t)row_sent[r] * 64 + pos[r]) * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] *= drop_factor(dr, base + j);
+  *(f32x4*)(out + (size_t)r * 256 + lane * 4) = *(const f32x4*)(x + (size_t)r * 256 + lane * 4) + v;
+}
+// dy = dropout'(dout)
+__global__ __launch_bounds__(256) void ae_resid_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ pos,
+                                                           const int32_t* __restrict__ row_sent, int n, Drop dr,
+                                                           float* __restrict__ dy) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 v = *(const f32x4*)(dout + (size_t)r * 256 + lane * 4);
+  const uint64_t base = ((uint64_t)row_sent[r] * 64 + pos[r]) * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] *= drop_factor(dr, base + j);
+  *(f32x4*)(dy + (size_t)r * 256 + lane * 4) = v;
+}
+// h = dropout(relu(h)) in place, width dff  (PositionwiseFeedForward, model.py:71-72)
+__global__ __launch_bounds__(256) void ae_relu_drop_kernel(float* __restrict__ h, const int32_t* __restrict__ pos,
+                                                           const int32_t* __restrict__ row_sent, int n, int dff, Drop dr) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)n * dff) return;
+  const int r = (int)(e / dff), c = (int)(e % dff);
+  const float v = fmaxf(h[e], 0.0f);
+  h[e] = v * drop_factor(dr, ((uint64_t)row_sent[r] * 64 + pos[r]) * dff + c);
+}
+// dh *= [h_post > 0] * scale  (h_post > 0 iff relu passed AND the unit was kept)
+__global__ __launch_bounds__(256) void ae_relu_drop_bwd_kernel(float* __restrict__ dh, const float* __restrict__ hpost, long n,
+                                                               float scale) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  dh[e] = hpost[e] > 0.0f ? dh[e] * scale : 0.0f;
+}
+__global__ __launch_bounds__(256) void ae_add_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) a[e] += b[e];
+}
+
+// latent[s] = sum over the sentence's rows of sigmoid(y[row])     (model.py:236-240)  block per sentence, thread = feature
+__global__ __launch_bounds__(256) void ae_latent_kernel(const float* __restrict__ y, const int32_t* __restrict__ off, int n_sent,
+                                                        float* __restrict__ lat) {
+  const int s = blockIdx.x, c = threadIdx.x;
+  float acc = 0.0f;
+  for (int r = off[s]; r < off[s + 1]; ++r) acc += 1.0f / (1.0f + expf(-y[(size_t)r * 256 + c]));
+  lat[(size_t)s * 256 + c] = acc;
+}
+__global__ __launch_bounds__(256) void ae_latent_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dlat,
+                                                            const int32_t* __restrict__ off, int n_sent, float* __restrict__ dy) {
+  const int s = blockIdx.x, c = threadIdx.x;
+  const float g = dlat[(size_t)s * 256 + c];
+  for (int r = off[s]; r < off[s + 1]; ++r) {
+    const float sg = 1.0f / (1.0f + expf(-y[(size_t)r * 256 + c]));
+    dy[(size_t)r * 256 + c] = g * sg * (1.0f - sg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-attention of one (sentence, head): L <= 64 positions, d_k = 64 (model.py:18-60).  One wave; lane = query row
+// (forward, dq) resp. key row (dk, dv).  P (softmax, before dropout) is saved [row][head][64] for the backward pass.
+// ------------------------------------------------------------------------------------------------
+#define ATT_TILE (64 * 65)
+__global__ __launch_bounds__(64) void ae_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const int32_t* __restrict__ off,
+                                                         int causal, Drop dr, float* __restrict__ P, float* __restrict__ out) {
+  extern __shared__ float sm[];
+  float* Ks = sm;             // [64][65]
+  float* Vs = sm + ATT_TILE;
+  const int s = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
+  const int r0 = off[s], L = off[s + 1] - r0;
+  for (int e = i; e < L * 64; e += 64) {
+    const int j = e >> 6, d = e & 63;
+    Ks[j * 65 + d] = k[(size_t)(r0 + j) * 256 + h * 64 + d];
+    Vs[j * 65 + d] = v[(size_t)(r0 + j) * 256 + h * 64 + d];
+  }
+  __syncthreads();
+  if (i >= L) return;
+  float qi[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) qi[d] = q[(size_t)(r0 + i) * 256 + h * 64 + d];
+  float* Pi = P + ((size_t)(r0 + i) * 4 + h) * 64;
+  const int nk = causal ? i + 1 : L;
+  float m = -INFINITY;
+  for (int j = 0; j < nk; ++j) {
+    float sc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) sc = fmaf(qi[d], Ks[j * 65 + d], sc);
+    sc *= 0.125f;
+    Pi[j] = sc;
+    m = fmaxf(m, sc);
+  }
+  float sum = 0.0f;
+  for (int j = 0; j < nk; ++j) {
+    const float e = expf(Pi[j] - m);
+    Pi[j] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / sum;
+  float o[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) o[d] = 0.0f;
+  const uint64_t base = (((uint64_t)s * 4 + h) * 64 + i) * 64;
+  for (int j = 0; j < nk; ++j) {
+    const float p = Pi[j] * inv;
+    Pi[j] = p;
+    const float pd = p * drop_factor(dr, base + j);
+#pragma unroll
+    for (int d = 0; d < 64; ++d) o[d] = fmaf(pd, Vs[j * 65 + d], o[d]);
+  }
+  for (int j = nk; j < 64; ++j) Pi[j] = 0.0f;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) out[(size_t)(r0 + i) * 256 + h * 64 + d] = o[d];
+}
+
+__global__ __launch_bounds__(64) void ae_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ P,
+                                                         const float* __restrict__ dout, const int32_t* __restrict__ off,
+                                                         int causal, Drop dr, float* __restrict__ dq, float* __restrict__ dk,
+                                                         float* __restrict__ dv) {
+  extern __shared__ float sm[];
+  float* Ks = sm;                 // [64][65]
+  float* Vs = sm + ATT_TILE;
+  float* Qs = sm + 2 * ATT_TILE;
+  float* Gs = sm + 3 * ATT_TILE;  // d out
+  float* Ss = sm + 4 * ATT_TILE;  // dS [query][key]
+  float* Ds = sm + 5 * ATT_TILE;  // dropped P [query][key]
+  const int s = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
+  const int r0 = off[s], L = off[s + 1] - r0;
+  for (int e = i; e < L * 64; e += 64) {
+    const int j = e >> 6, d = e & 63;
+    const size_t g = (size_t)(r0 + j) * 256 + h * 64 + d;
+    Ks[j * 65 + d] = k[g];
+    Vs[j * 65 + d] = v[g];
+    Qs[j * 65 + d] = q[g];
+    Gs[j * 65 + d] = dout[g];
+  }
+  for (int e = i; e < 64 * 65; e += 64) Ss[e] = Ds[e] = 0.0f;
+  __syncthreads();
+  if (i < L) {
+    const float* Pi = P + ((size_t)(r0 + i) * 4 + h) * 64;
+    const int nk = causal ? i + 1 : L;
+    const uint64_t base = (((uint64_t)s * 4 + h) * 64 + i) * 64;
+    float dot = 0.0f;
+    for (int j = 0; j < nk; ++j) {
+      float dpd = 0.0f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) dpd = fmaf(Gs[i * 65 + d], Vs[j * 65 + d], dpd);
+      const float f = drop_factor(dr, base + j);
+      const float dp = dpd * f;
+      Ds[i * 65 + j] = Pi[j] * f;
+      Ss[i * 65 + j] = dp;
+      dot = fmaf(dp, Pi[j], dot);
+    }
+    float dqi[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) dqi[d] = 0.0f;
+    for (int j = 0; j < nk; ++j) {
+      const float ds = Pi[j] * (Ss[i * 65 + j] - dot) * 0.125f;  // d score (the 1/sqrt(d_k) folded in)
+      Ss[i * 65 + j] = ds;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) dqi[d] = fmaf(ds, Ks[j * 65 + d], dqi[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < 64; ++d) dq[(size_t)(r0 + i) * 256 + h * 64 + d] = dqi[d];
+  }
+  __syncthreads();
+  if (i < L) {  // lane = key row j
+    float dkj[64], dvj[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) dkj[d] = dvj[d] = 0.0f;
+    for (int qi = 0; qi < L; ++qi) {
+      const float ds = Ss[qi * 65 + i], pd = Ds[qi * 65 + i];
+#pragma unroll
+      for (int d = 0; d < 64; ++d) {
+        dkj[d] = fmaf(ds, Qs[qi * 65 + d], dkj[d]);
+        dvj[d] = fmaf(pd, Gs[qi * 65 + d], dvj[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+      dk[(size_t)(r0 + i) * 256 + h * 64 + d] = dkj[d];
+      dv[(size_t)(r0 + i) * 256 + h * 64 + d] = dvj[d];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder source attention over ONE memory position (model.py:195, :264-269): softmax == 1, so the attended value of
+// row r is c[sentence(r)] = Wv latent + bv, times the p_attn dropout factor of (row, head)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ae_src_gather_kernel(const float* __restrict__ c, const int32_t* __restrict__ pos,
+                                                            const int32_t* __restrict__ row_sent, int n, Drop dr,
+                                                            float* __restrict__ u) {
+  const int r = blockIdx.x, t = threadIdx.x;
+  if (r >= n) return;
+  const int s = row_sent[r];
+  u[(size_t)r * 256 + t] = c[(size_t)s * 256 + t] * drop_factor(dr, ((uint64_t)s * 64 + pos[r]) * 4 + (t >> 6));
+}
+// dc[s] = sum over the sentence's rows of du[row] * factor(row, head)
+__global__ __launch_bounds__(256) void ae_src_gather_bwd_kernel(const float* __restrict__ du, const int32_t* __restrict__ pos,
+                                                                const int32_t* __restrict__ off, int n_sent, Drop dr,
+                                                                float* __restrict__ dc) {
+  const int s = blockIdx.x, t = threadIdx.x;
+  float acc = 0.0f;
+  for (int r = off[s]; r < off[s + 1]; ++r)
+    acc += du[(size_t)r * 256 + t] * drop_factor(dr, ((uint64_t)s * 64 + pos[r]) * 4 + (t >> 6));
+  dc[(size_t)s * 256 + t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generator + LabelSmoothing (model.py:200-207, :389-411): per row  loss = sum_v t_v (log t_v - logp_v),
+// t = confidence at the target, smoothing / (V - 2) elsewhere, 0 at PAD;  logits <- (softmax - t) * gscale  in place
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ae_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ target, int n, int V,
+                                                      int pad, float smoothing, float gscale, float* __restrict__ row_loss) {
+  __shared__ float red[256];
+  const int r = blockIdx.x, t = threadIdx.x;
+  float* x = logits + (size_t)r * V;
+  float m = -INFINITY;
+  for (int c = t; c < V; c += 256) m = fmaxf(m, x[c]);
+  red[t] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  float se = 0.0f, sx = 0.0f;
+  for (int c = t; c < V; c += 256) {
+    se += expf(x[c] - m);
+    sx += x[c];
+  }
+  red[t] = se;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const float lse = m + logf(red[0]);
+  __syncthreads();
+  red[t] = sx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const float sumx = red[0];
+  const int y = target[r];
+  const bool live = y != pad;
+  const float sv = smoothing / (float)(V - 2), conf = 1.0f - smoothing;
+  if (t == 0) {
+    float l = 0.0f;
+    if (live) {
+      // sum_v t_v log t_v  -  sum_v t_v logp_v,  logp_v = x_v - lse;  "others" = all v except the target and PAD
+      const float so = sumx - x[y] - x[pad] - (float)(V - 2) * lse;
+      l = conf * logf(conf) + (smoothing > 0.0f ? smoothing * logf(sv) : 0.0f) - conf * (x[y] - lse) - sv * so;
+    }
+    row_loss[r] = l;
+  }
+  __syncthreads();
+  for (int c = t; c < V; c += 256) {
+    float g = 0.0f;
+    if (live) {
+      const float tv = c == y ? conf : (c == pad ? 0.0f : sv);
+      g = (expf(x[c] - lse) - tv) * gscale;
+    }
+    x[c] = g;
+  }
+}
+// out[0] = scale * sum(v[0..n))   (one block; fixed order per thread, tree over threads)
+__global__ __launch_bounds__(256) void ae_sum_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+__global__ void ae_fill_kernel(float* p, long n, float v) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) p[e] = v;
+}
+__global__ void ae_row_sent_kernel(const int32_t* __restrict__ off, int n_sent, int32_t* __restrict__ row_sent) {
+  const int s = blockIdx.x;
+  for (int r = off[s] + threadIdx.x; r < off[s + 1]; r += blockDim.x) row_sent[r] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+inline size_t up256(size_t b) { return (b + 255) / 256 * 256; }
+struct Arena {
+  char* base;
+  size_t off;
+  float* f(size_t n) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += up256(n * 4);
+    return p;
+  }
+};
+struct LayerSave {
+  float *x_in, *n0, *q, *k, *v, *P, *att, *x1, *u, *x2, *n2, *h;  // u / x2: decoder only (source-attention sublayer)
+};
+struct Ws {
+  // encoder (Re rows), decoder (Rd rows)
+  int32_t *e_row_sent, *d_row_sent;
+  LayerSave enc[ST_MAX_LAYERS], dec[ST_MAX_LAYERS];
+  float *e_x, *e_y, *lat, *dlat;                 // encoder output before / after the final norm, latents and their gradient
+  float *d_x, *d_xn, *logits, *row_loss, *cc[ST_MAX_LAYERS], *dcc;
+  float *ta, *tb, *tc, *td, *th;                 // scratch activations / gradients [rows, 256] x4, [rows, d_ff]
+  float *sl_loss, *sl_lse, *sl_g, *sl_dori, *sl_dlike, *con_rows;
+  void* sl_scratch;
+  size_t sl_scratch_bytes;
+  size_t total;
+};
+
+Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
+  Ws w = {};
+  Arena a{base, 0};
+  const int L = p->n_layers, dff = p->d_ff, V = p->vocab;
+  const int R = Re > Rd ? Re : Rd;
+  w.e_row_sent = (int32_t*)a.f(Re);
+  w.d_row_sent = (int32_t*)a.f(Rd);
+  for (int l = 0; l < L; ++l) {
+    LayerSave& s = w.enc[l];
+    s.x_in = a.f((size_t)Re * 256); s.n0 = a.f((size_t)Re * 256); s.q = a.f((size_t)Re * 256); s.k = a.f((size_t)Re * 256);
+    s.v = a.f((size_t)Re * 256); s.P = a.f((size_t)Re * 256); s.att = a.f((size_t)Re * 256); s.x1 = a.f((size_t)Re * 256);
+    s.n2 = a.f((size_t)Re * 256); s.h = a.f((size_t)Re * dff);
+    LayerSave& d = w.dec[l];
+    d.x_in = a.f((size_t)Rd * 256); d.n0 = a.f((size_t)Rd * 256); d.q = a.f((size_t)Rd * 256); d.k = a.f((size_t)Rd * 256);
+    d.v = a.f((size_t)Rd * 256); d.P = a.f((size_t)Rd * 256); d.att = a.f((size_t)Rd * 256); d.x1 = a.f((size_t)Rd * 256);
+    d.u = a.f((size_t)Rd * 256); d.x2 = a.f((size_t)Rd * 256); d.n2 = a.f((size_t)Rd * 256); d.h = a.f((size_t)Rd * dff);
+    w.cc[l] = a.f((size_t)B * 256);
+  }
+  w.e_x = a.f((size_t)Re * 256); w.e_y = a.f((size_t)Re * 256);
+  w.lat = a.f((size_t)Se * 256); w.dlat = a.f((size_t)Se * 256);
+  w.d_x = a.f((size_t)Rd * 256); w.d_xn = a.f((size_t)Rd * 256);
+  w.logits = a.f((size_t)Rd * V); w.row_loss = a.f(Rd); w.dcc = a.f((size_t)B * 256);
+  w.ta = a.f((size_t)R * 256); w.tb = a.f((size_t)R * 256); w.tc = a.f((size_t)R * 256); w.td = a.f((size_t)R * 256);
+  w.th = a.f((size_t)R * dff);
+  w.sl_loss = a.f(B); w.sl_lse = a.f(B); w.sl_g = a.f(B); w.sl_dori = a.f((size_t)B * 256); w.sl_dlike = a.f((size_t)B * 256);
+  w.con_rows = a.f((size_t)(Se / (B > 0 ? B : 1)) * B);
+  w.sl_scratch_bytes = st_simloss_scratch_bytes(B, B);
+  w.sl_scratch = base ? base + a.off : nullptr;
+  a.off += up256(w.sl_scratch_bytes);
+  w.total = a.off;
+  return w;
+}
+
+struct Ctx {
+  hipStream_t st;
+  int rc;
+  int gemm(const float* A, long sai, long sar, const float* Bm, long sbr, long sbj, float* C, int ldc, const float* bias, int M, int N,
+           int R, int accumulate) {
+    if (M <= 0 || N <= 0) return ST_OK;
+    GArgs a{A, Bm, C, bias, M, N, R, sai, sar, sbr, sbj, ldc, accumulate};
+    hipLaunchKernelGGL(ae_gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, a);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
+  // Y[rows,N] = X[rows,K] W^T + b      (W row-major [N,K])
+  int lin(const float* X, const float* W, const float* b, float* Y, int rows, int N, int K) {
+    return gemm(X, K, 1, W, 1, K, Y, N, b, rows, N, K, 0);
+  }
+  // dX (+)= dY W;  dW = dY^T X;  db = column sums of dY
+  int lin_bwd(const float* dY, const float* X, const float* W, float* dX, int acc_dx, float* dW, float* db, int rows, int N, int K) {
+    if (dX) ST_TRY(gemm(dY, N, 1, W, K, 1, dX, K, nullptr, rows, K, N, acc_dx));
+    if (dW) ST_TRY(gemm(dY, 1, N, X, K, 1, dW, K, nullptr, N, K, rows, 0));
+    if (db) {
+      hipLaunchKernelGGL(ae_colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, dY, rows, N, db);
+      ST_LAUNCH_CHECK();
+    }
+    return ST_OK;
+  }
+};
+
+#define ROWS4(n) dim3(((n) + 3) / 4), dim3(256), 0, c.st
+#define ELEMS(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, c.st
+
+}  // namespace
+
+extern "C" size_t st_ae_train_workspace_bytes(const StAeParams* p, int n_enc_rows, int n_enc_sent, int n_dec_rows, int B) {
+  if (!p || n_enc_rows <= 0 || n_enc_sent <= 0 || n_dec_rows <= 0 || B <= 0) return 0;
+  return carve(p, n_enc_rows, n_enc_sent, n_dec_rows, B, nullptr).total;
+}
+
+extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float* grads_flat, int64_t n_params,
+                                const int32_t* enc_tokens, const int32_t* enc_pos, const int32_t* enc_off, int n_enc_rows,
+                                int n_enc_sent, const int32_t* dec_tokens, const int32_t* dec_pos, const int32_t* dec_targets,
+                                const int32_t* dec_off, int n_dec_rows, int B, float bata, float tau, float smoothing,
+                                float drop_p, uint64_t seed, float* losses_out, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  ST_CHECK_ARG(p && g && grads_flat && n_params > 0, "NULL parameter / gradient structs");
+  ST_CHECK_ARG(p->d_model == ST_D && p->n_heads == 4, "d_model=%d n_heads=%d unsupported (256, 4)", p->d_model, p->n_heads);
+  ST_CHECK_ARG(p->n_layers >= 1 && p->n_layers <= ST_MAX_LAYERS && p->d_ff > 0 && p->vocab >= 4, "n_layers=%d d_ff=%d vocab=%d",
+               p->n_layers, p->d_ff, p->vocab);
+  ST_CHECK_ARG(B >= 1 && n_enc_sent >= 2 * B && n_enc_sent % B == 0, "n_enc_sent=%d must be (1 + views) * B with views >= 1 (B=%d)",
+               n_enc_sent, B);
+  ST_CHECK_ARG(n_enc_rows > 0 && n_dec_rows > 0, "empty batch");
+  ST_CHECK_ARG(enc_tokens && enc_pos && enc_off && dec_tokens && dec_pos && dec_targets && dec_off && losses_out && workspace,
+               "NULL buffer");
+  ST_CHECK_ARG(drop_p >= 0.0f && drop_p < 1.0f && tau > 0.0f, "drop_p=%g tau=%g", (double)drop_p, (double)tau);
+  Ws w = carve(p, n_enc_rows, n_enc_sent, n_dec_rows, B, (char*)workspace);
+  if (w.total > workspace_bytes) {
+    st_set_error("st_ae_train_step: workspace too small: need %zu bytes, have %zu", w.total, workspace_bytes);
+    return ST_ENOMEM;
+  }
+  Ctx c{(hipStream_t)stream, 0};
+  const int Re = n_enc_rows, Se = n_enc_sent, Rd = n_dec_rows, L = p->n_layers, dff = p->d_ff, V = p->vocab;
+  const int n_views = Se / B - 1;
+  auto drop = [&](uint32_t site) { return Drop{seed, drop_p, drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f, site}; };
+  const size_t att_fwd_lds = 2 * ATT_TILE * 4, att_bwd_lds = 6 * ATT_TILE * 4;
+  ST_ENSURE_LDS(ae_attn_bwd_kernel, (int)att_bwd_lds);
+
+  ST_HIP(hipMemsetAsync(grads_flat, 0, (size_t)n_params * 4, c.st));
+  hipLaunchKernelGGL(ae_row_sent_kernel, dim3(Se), dim3(64), 0, c.st, enc_off, Se, w.e_row_sent);
+  hipLaunchKernelGGL(ae_row_sent_kernel, dim3(B), dim3(64), 0, c.st, dec_off, B, w.d_row_sent);
+  ST_LAUNCH_CHECK();
+
+  // one pre-norm transformer layer, forward.  dec: with the source-attention sublayer between the two
+  auto layer_fwd = [&](const StAeLayer& y, LayerSave& s, const float* x, float* x_out, int rows, int n_sent, const int32_t* off,
+                       const int32_t* pos, const int32_t* row_sent, bool dec, uint32_t site0, const float* cconst) -> int {
+    ST_HIP(hipMemcpyAsync(s.x_in, x, (size_t)rows * 1024, hipMemcpyDeviceToDevice, c.st));
+    hipLaunchKernelGGL(ae_ln_fwd_kernel, ROWS4(rows), s.x_in, y.ln0_a, y.ln0_b, rows, s.n0);
+    ST_TRY(c.lin(s.n0, y.wq, y.bq, s.q, rows, 256, 256));
+    ST_TRY(c.lin(s.n0, y.wk, y.bk, s.k, rows, 256, 256));
+    ST_TRY(c.lin(s.n0, y.wv, y.bv, s.v, rows, 256, 256));
+    hipLaunchKernelGGL(ae_attn_fwd_kernel, dim3(n_sent, 4), dim3(64), att_fwd_lds, c.st, s.q, s.k, s.v, off, dec ? 1 : 0,
+                       drop(site0 + 0), s.P, s.att);
+    ST_LAUNCH_CHECK();
+    ST_TRY(c.lin(s.att, y.wo, y.bo, w.ta, rows, 256, 256));
+    hipLaunchKernelGGL(ae_resid_kernel, ROWS4(rows), s.x_in, w.ta, pos, row_sent, rows, drop(site0 + 1), s.x1);
+    const float* xm = s.x1;
+    uint32_t site = site0 + 2;
+    if (dec) {
+      hipLaunchKernelGGL(ae_src_gather_kernel, dim3(rows), dim3(256), 0, c.st, cconst, pos, row_sent, rows, drop(site0 + 2), s.u);
+      ST_TRY(c.lin(s.u, y.xo_w, y.xo_b, w.ta, rows, 256, 256));
+      hipLaunchKernelGGL(ae_resid_kernel, ROWS4(rows), s.x1, w.ta, pos, row_sent, rows, drop(site0 + 3), s.x2);
+      xm = s.x2;
+      site = site0 + 4;
+    }
+    hipLaunchKernelGGL(ae_ln_fwd_kernel, ROWS4(rows), xm, y.ln2_a, y.ln2_b, rows, s.n2);
+    ST_TRY(c.lin(s.n2, y.w1, y.b1, s.h, rows, dff, 256));
+    hipLaunchKernelGGL(ae_relu_drop_kernel, ELEMS((long)rows * dff), s.h, pos, row_sent, rows, dff, drop(site));
+    ST_TRY(c.lin(s.h, y.w2, y.b2, w.ta, rows, 256, dff));
+    hipLaunchKernelGGL(ae_resid_kernel, ROWS4(rows), xm, w.ta, pos, row_sent, rows, drop(site + 1), x_out);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  };
+  // backward of the same layer: dx holds d(layer output) on entry and d(layer input) on exit
+  auto layer_bwd = [&](const StAeLayer& y, const StAeLayer& gy, LayerSave& s, float* dx, int rows, int n_sent, const int32_t* off,
+                       const int32_t* pos, const int32_t* row_sent, bool dec, uint32_t site0, const float* latent_ori,
+                       float* dlat_ori) -> int {
+    const float* xm = dec ? s.x2 : s.x1;
+    const uint32_t site = dec ? site0 + 4 : site0 + 2;
+    const float scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    // feed-forward sublayer
+    hipLaunchKernelGGL(ae_resid_bwd_kernel, ROWS4(rows), dx, pos, row_sent, rows, drop(site + 1), w.ta);
+    ST_TRY(c.lin_bwd(w.ta, s.h, y.w2, w.th, 0, (float*)gy.w2, (float*)gy.b2, rows, 256, dff));
+    hipLaunchKernelGGL(ae_relu_drop_bwd_kernel, ELEMS((long)rows * dff), w.th, s.h, (long)rows * dff, scale);
+    ST_TRY(c.lin_bwd(w.th, s.n2, y.w1, w.tb, 0, (float*)gy.w1, (float*)gy.b1, rows, dff, 256));
+    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, xm, y.ln2_a, rows, dx, 1, (float*)gy.ln2_a, (float*)gy.ln2_b);
+    if (dec) {
+      // source attention: x2 = x1 + drop(u Wo^T + bo), u = c[sentence] * head factor; no gradient reaches q / k / norm
+      hipLaunchKernelGGL(ae_resid_bwd_kernel, ROWS4(rows), dx, pos, row_sent, rows, drop(site0 + 3), w.ta);
+      ST_TRY(c.lin_bwd(w.ta, s.u, y.xo_w, w.tb, 0, (float*)gy.xo_w, (float*)gy.xo_b, rows, 256, 256));
+      hipLaunchKernelGGL(ae_src_gather_bwd_kernel, dim3(n_sent), dim3(256), 0, c.st, w.tb, pos, off, n_sent, drop(site0 + 2), w.dcc);
+      ST_TRY(c.lin_bwd(w.dcc, latent_ori, y.xv_w, dlat_ori, 1, (float*)gy.xv_w, (float*)gy.xv_b, n_sent, 256, 256));
+    }
+    // self-attention sublayer
+    hipLaunchKernelGGL(ae_resid_bwd_kernel, ROWS4(rows), dx, pos, row_sent, rows, drop(site0 + 1), w.ta);
+    ST_TRY(c.lin_bwd(w.ta, s.att, y.wo, w.tb, 0, (float*)gy.wo, (float*)gy.bo, rows, 256, 256));
+    hipLaunchKernelGGL(ae_attn_bwd_kernel, dim3(n_sent, 4), dim3(64), att_bwd_lds, c.st, s.q, s.k, s.v, s.P, w.tb, off, dec ? 1 : 0,
+                       drop(site0 + 0), w.ta, w.tc, w.td);
+    ST_LAUNCH_CHECK();
+    ST_TRY(c.lin_bwd(w.ta, s.n0, y.wq, w.tb, 0, (float*)gy.wq, (float*)gy.bq, rows, 256, 256));
+    ST_TRY(c.lin_bwd(w.tc, s.n0, y.wk, w.tb, 1, (float*)gy.wk, (float*)gy.bk, rows, 256, 256));
+    ST_TRY(c.lin_bwd(w.td, s.n0, y.wv, w.tb, 1, (float*)gy.wv, (float*)gy.bv, rows, 256, 256));
+    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, s.x_in, y.ln0_a, rows, dx, 1, (float*)gy.ln0_a, (float*)gy.ln0_b);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  };
+
+  // ---------------- encoder forward over all (1 + views) * B sentences ----------------
+  hipLaunchKernelGGL(ae_embed_kernel, ROWS4(Re), p->emb, p->pe, enc_tokens, enc_pos, w.e_row_sent, Re, V, drop(1), w.e_x);
+  for (int l = 0; l < L; ++l)
+    ST_TRY(layer_fwd(p->enc[l], w.enc[l], w.e_x, w.e_x, Re, Se, enc_off, enc_pos, w.e_row_sent, false, 10 + 4 * l, nullptr));
+  hipLaunchKernelGGL(ae_ln_fwd_kernel, ROWS4(Re), w.e_x, p->enc_norm_a, p->enc_norm_b, Re, w.e_y);
+  hipLaunchKernelGGL(ae_latent_kernel, dim3(Se), dim3(256), 0, c.st, w.e_y, enc_off, Se, w.lat);
+  ST_LAUNCH_CHECK();
+  // ---------------- decoder forward (teacher forced) on the origins' latents ----------------
+  hipLaunchKernelGGL(ae_embed_kernel, ROWS4(Rd), p->emb, p->pe, dec_tokens, dec_pos, w.d_row_sent, Rd, V, drop(2), w.d_x);
+  for (int l = 0; l < L; ++l) {
+    ST_TRY(c.lin(w.lat, p->dec[l].xv_w, p->dec[l].xv_b, w.cc[l], B, 256, 256));
+    ST_TRY(layer_fwd(p->dec[l], w.dec[l], w.d_x, w.d_x, Rd, B, dec_off, dec_pos, w.d_row_sent, true, 100 + 6 * l, w.cc[l]));
+  }
+  hipLaunchKernelGGL(ae_ln_fwd_kernel, ROWS4(Rd), w.d_x, p->dec_norm_a, p->dec_norm_b, Rd, w.d_xn);
+  ST_TRY(c.lin(w.d_xn, p->gen_w, p->gen_b, w.logits, Rd, V, 256));
+  // every packed decoder row has a non-PAD target (tokens, then EOS): ntokens = Rd  (siamese_contrastive.py:1040-1041)
+  hipLaunchKernelGGL(ae_xent_kernel, dim3(Rd), dim3(256), 0, c.st, w.logits, dec_targets, Rd, V, 0, smoothing, 1.0f / (float)Rd, w.row_loss);
+  hipLaunchKernelGGL(ae_sum_kernel, dim3(1), dim3(256), 0, c.st, w.row_loss, Rd, 1.0f / (float)Rd, losses_out + 0);
+  ST_LAUNCH_CHECK();
+  // ---------------- constraint: the (views) B x B similarity blocks ----------------
+  ST_HIP(hipMemsetAsync(w.dlat, 0, (size_t)Se * 1024, c.st));
+  hipLaunchKernelGGL(ae_fill_kernel, ELEMS((long)B), w.sl_g, (long)B, bata / ((float)B * (float)n_views));
+  for (int v = 0; v < n_views; ++v) {
+    const float* like = w.lat + (size_t)(1 + v) * B * 256;
+    float* dlike = w.dlat + (size_t)(1 + v) * B * 256;
+    ST_TRY(st_simloss_fwd(w.lat, like, B, B, tau, 0, w.con_rows + (size_t)v * B, w.sl_lse, w.sl_scratch, w.sl_scratch_bytes, c.st));
+    if (B % 32 == 0) {
+      ST_TRY(st_simloss_bwd(w.lat, like, B, B, tau, 0, w.sl_lse, w.sl_g, w.sl_dori, dlike, w.sl_scratch, w.sl_scratch_bytes, c.st));
+      hipLaunchKernelGGL(ae_add_kernel, ELEMS((long)B * 256), w.dlat, w.sl_dori, (long)B * 256);
+      ST_LAUNCH_CHECK();
+    } else {
+      st_set_error("st_ae_train_step: the similarity block's backward needs B %% 32 == 0 (B=%d)", B);
+      return ST_EINVAL;
+    }
+  }
+  hipLaunchKernelGGL(ae_sum_kernel, dim3(1), dim3(256), 0, c.st, w.con_rows, n_views * B, 1.0f / ((float)B * (float)n_views), losses_out + 1);
+  ST_LAUNCH_CHECK();
+  // ---------------- decoder backward ----------------
+  {
+    float* dx = w.d_x;  // the residual stream buffer becomes the running gradient (its value moves to td first)
+    ST_TRY(c.lin_bwd(w.logits, w.d_xn, p->gen_w, w.tb, 0, (float*)g->gen_w, (float*)g->gen_b, Rd, V, 256));
+    // the final norm's input is still needed by its backward: keep it in td
+    ST_HIP(hipMemcpyAsync(w.td, w.d_x, (size_t)Rd * 1024, hipMemcpyDeviceToDevice, c.st));
+    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, w.td, p->dec_norm_a, Rd, dx, 0, (float*)g->dec_norm_a, (float*)g->dec_norm_b);
+    ST_LAUNCH_CHECK();
+    for (int l = L - 1; l >= 0; --l)
+      ST_TRY(layer_bwd(p->dec[l], g->dec[l], w.dec[l], dx, Rd, B, dec_off, dec_pos, w.d_row_sent, true, 100 + 6 * l, w.lat, w.dlat));
+    hipLaunchKernelGGL(ae_embed_bwd_kernel, ROWS4(Rd), dx, dec_tokens, dec_pos, w.d_row_sent, Rd, V, drop(2), (float*)g->emb);
+    ST_LAUNCH_CHECK();
+  }
+  // ---------------- encoder backward ----------------
+  {
+    float* dx = w.e_x;
+    ST_HIP(hipMemcpyAsync(w.td, w.e_x, (size_t)Re * 1024, hipMemcpyDeviceToDevice, c.st));
+    hipLaunchKernelGGL(ae_latent_bwd_kernel, dim3(Se), dim3(256), 0, c.st, w.e_y, w.dlat, enc_off, Se, w.tb);
+    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, w.td, p->enc_norm_a, Re, dx, 0, (float*)g->enc_norm_a, (float*)g->enc_norm_b);
+    ST_LAUNCH_CHECK();
+    for (int l = L - 1; l >= 0; --l)
+      ST_TRY(layer_bwd(p->enc[l], g->enc[l], w.enc[l], dx, Re, Se, enc_off, enc_pos, w.e_row_sent, false, 10 + 4 * l, nullptr, nullptr));
+    hipLaunchKernelGGL(ae_embed_bwd_kernel, ROWS4(Re), dx, enc_tokens, enc_pos, w.e_row_sent, Re, V, drop(1), (float*)g->emb);
+    ST_LAUNCH_CHECK();
+  }
+  return ST_OK;
+}

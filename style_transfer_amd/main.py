@@ -99,6 +99,11 @@ def build_parser():
     g.add_argument('--train_files', type=str, default='neg10_pos10_train0.json,neg10_pos10_train1.json',
                    help='training records under --data_path (siamese_contrastive.py:234-239; same schema as the test files)')
     g.add_argument('--init_seed', type=int, default=None, help='seed of the fresh SiameseNet / Predictor weights')
+    g.add_argument('--train_ae', action='store_true',
+                   help="run train_ae_model_constraint (main.py:470-471: the branch taken when no checkpoint is loaded) on "
+                        "ae_train_constraint{0,1}.json under --data_path, starting from --ae_checkpoint when it exists, else "
+                        "from make_model's initialisation; writes constraint_ae_model<epoch>_params.pkl under --save_path")
+    g.add_argument('--ae_epochs', type=int, default=1, help='epochs of --train_ae (train_ae_model_constraint default: 1)')
     return p
 
 
@@ -195,6 +200,32 @@ def train_scorer_main(args, ae, vocab_size, data_path, save_path, device, rank, 
     return 0
 
 
+def train_ae_main(args, vocab_size, data_path, save_path, device, rank, world, log):
+    """--train_ae: the autoencoder's constraint training (siamese_contrastive.py:1000-1088) on the HIP step"""
+    from . import weights as W
+    from .data import AttackSet
+    from .train_ae import AETrainConfig, AETrainer, fresh_ae_state_dict, train_ae_model_constraint
+    if world > 1:
+        raise SystemExit("--train_ae runs on one GPU (the in-batch constraint couples the rows of a batch; the N-GPU form of "
+                         "the similarity block is contrastive.constraint_loss_and_grads)")
+    ck = os.path.join(save_path, args.ae_checkpoint)
+    if os.path.exists(ck):
+        sd = W.expand_ae_state_dict(W.load_state_dict_file(ck))
+    else:
+        sd = fresh_ae_state_dict(vocab_size, args.num_layers_AE, args.transformer_model_size, args.transformer_ff_size, args.init_seed)
+    files = [os.path.join(data_path, 'ae_train_constraint0.json'), os.path.join(data_path, 'ae_train_constraint1.json')]
+    log('Loading Dataset, Shuffle=True')
+    log('ori_file_list = {}'.format(files))
+    print('Random Seed is set to 234')
+    data = AttackSet.from_json(files, vocab_size, args.id_unk, args.max_sequence_length, args.pos_num, 0)
+    trainer = AETrainer(sd, AETrainConfig(bata=args.bata, tau=args.tau), device)
+    os.makedirs(save_path, exist_ok=True)
+    train_ae_model_constraint(trainer, data, args.batch_size, args.ae_epochs, log, save_path)
+    log.close()
+    print('Done')
+    return 0
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     args.if_load_from_checkpoint = True        # main.py:130-131
@@ -250,6 +281,8 @@ def main(argv=None):
         print("prepare data ...")
     id_to_word, vocab_size = load_word_dict_info(os.path.join(data_path, 'word_to_id.txt'), args.word_dict_max_num)
 
+    if args.train_ae:
+        return train_ae_main(args, vocab_size, data_path, save_path, device, rank, world, log)
     ae_sd = W.load_state_dict_file(os.path.join(save_path, args.ae_checkpoint))
     ae = W.AEWeights(ae_sd, device, max_len=args.max_sequence_length, gemm_format=args.gemm_format)
     if ae.vocab != vocab_size:

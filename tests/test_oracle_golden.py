@@ -151,3 +151,38 @@ def test_scorer_train_step_oracle_vs_reference(tag, kw):
             np.testing.assert_allclose(steps[-1]["stats"][k[3:]], gd[k], rtol=0, atol=5e-3, err_msg=k)
         elif k.startswith("bn."):
             assert int(gd[k]) in (0, 3, 63)
+
+
+@pytest.mark.parametrize("tag", ["nodrop", "drop"])
+def test_ae_train_step_oracle_vs_reference(tag, ae_sd):
+    """The numpy restatement of the AE constraint-training step (oracle/st_ae_train_oracle.py) against the reference's
+    own train_ae_model_constraint run (tests/golden/ae_train_*.npz): both losses, every parameter's gradient (2-norm
+    per tensor + every 37th element), with dropout 0 and with the reference's 264 captured nn.Dropout masks replayed
+    in call order; parameter order; NoamOpt / Adam's first step."""
+    import st_ae_train_oracle as A
+    import ae_train_common as AC
+    from style_transfer_amd.train_ae import ae_param_names, noam_rate
+    g = gold("ae_train_%s.npz" % tag)
+    names = [str(n) for n in g["names"]]
+    assert names == ae_param_names(2)
+    sd = {k: v.astype(np.float64) for k, v in ae_sd.items()}
+    origin, views = AC.golden_batch(g, 0)
+    masks = AC.reference_masks(g) if tag == "drop" else None
+    rec, con, grads = A.train_step_loss_and_grads(sd, origin, views, float(g["bata"]), float(g["tau"]), masks, float(g["dropout"]))
+    assert abs(rec - g["rec_loss"][0]) < 1e-5 * abs(g["rec_loss"][0]) and abs(con - g["con_loss"][0]) < 1e-5 * g["con_loss"][0]
+    for i, n in enumerate(names):
+        ref = float(g["grad_norms"][0][i])
+        mine = float(np.linalg.norm(grads[n]))
+        if AC.is_noise(n) or AC.is_zero(n):
+            assert mine < 1e-6 and ref < 1e-6, (n, mine, ref)      # true gradient 0: the reference holds rounding noise
+        else:
+            assert abs(mine - ref) < 1e-4 * ref, (n, mine, ref)
+    flat = np.concatenate([grads[n].ravel() for n in names])
+    assert np.abs(flat[::37] - g["grad"][0]).max() < 5e-5 * np.abs(g["grad"][0]).max()   # the reference is f32
+    # NoamOpt: lr(1) = 256^-0.5 * 2000^-1.5; Adam's first step moves every parameter by lr * g / (|g| + eps)
+    lr = noam_rate(1)
+    assert abs(lr - float(g["lr"][0])) < 1e-12
+    p0 = np.concatenate([sd[n].ravel() for n in names])
+    p1, _, _ = A.adam_step(p0, flat, np.zeros_like(p0), np.zeros_like(p0), 1, lr)
+    sel = np.abs(flat[::37]) > 1e-6
+    assert np.abs(p1[::37][sel] - g["param"][0][sel]).max() < 2e-7
