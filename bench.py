@@ -71,7 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32768, help="sentences per GPU per step (KV cache: 241 KB per decode job, 13 jobs per sentence in the first round)")
+    ap.add_argument("--batch", type=int, default=49152,
+                    help="sentences per GPU per step (KV cache: 241 KB per decode job, 13 jobs per sentence in the first round: 154 GB of "
+                         "the 288 GB at the default; 32768 -> 113.6 k, 49152 -> 121.2 k, 65536 -> 123.0 k sentences/s)")
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
     ap.add_argument("--tokens", default="zipf", choices=["zipf", "uniform", "real"],
                     help="synthetic token ids: unigram (Zipfian) from word_to_id.txt counts, uniform in [4,V), or the "
@@ -336,7 +338,7 @@ def main(argv=None):
         if split and gen_n.value > 0:
             # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
             alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
-            default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 32768 and not a.fixed_steps
+            default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 49152 and not a.fixed_steps
                            and a.iters_per_decode == "12,6" and not a.log_decodes)
             if default_cfg and os.path.exists(tfile):
                 traffic = json.load(open(tfile))["bytes_per_launch"]
