@@ -220,6 +220,11 @@ int st_simloss_bwd(const float* ori, const float* like, int Bq, int Bk, float ta
                    const float* lse, const float* g, float* d_ori, float* d_like, void* scratch,
                    size_t scratch_bytes, void* stream);
 size_t st_simloss_scratch_bytes(int Bq, int Bk);
+/* Operand format of the similarity products (ST_GEMM_*; returns the previous one; unknown values change nothing).
+ * ST_GEMM_F16X3 (default): unit rows and dS' = exp(s - lse) - [target] lie in [-1, 1], so every product of the block
+ * (forward, and in the backward the dS', dS'^T, d_ori and d_like products when Bq and Bk are multiples of 256) runs as
+ * three f16 MFMA products of hi + lo split operands (f32-grade).  ST_GEMM_F32: exact f32 MFMA throughout.           */
+int st_simloss_format(int gemm_format);
 
 /* ---------------------------------------------------------------------------------------------
  * (6) Encoder -> latent, batched and length-packed (EncoderDecoder.forward's encoder half /

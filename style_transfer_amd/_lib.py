@@ -92,6 +92,7 @@ EXPORTS = {
     "st_gemm_argmax_noalloc": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]),
     "st_accept_changes": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp,
                                     fp, fp, fp, fp, fp]),
+    "st_simloss_format": (C.c_int, [C.c_int]),
     "st_simloss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "st_simloss_fwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, C.c_size_t, fp]),
     "st_simloss_bwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, fp, fp, C.c_size_t, fp]),

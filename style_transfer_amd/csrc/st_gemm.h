@@ -16,7 +16,7 @@
 #define ST_LDA 260  // panel row stride in floats (256 + 4)
 #define ST_LDW 36   // W-stage row stride in floats (32 + 4)
 
-enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_QKV = 3, EPI_ARGMAX = 4, EPI_LSE = 5, EPI_DS = 6 };
+enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_QKV = 3, EPI_ARGMAX = 4, EPI_LSE = 5, EPI_DS = 6, EPI_DST = 7 };
 
 struct GemmArgs {
   const float* X;      // [n, K] row-major
@@ -45,7 +45,8 @@ struct GemmArgs {
   float4* partial;
   // LSE / DS (in-batch InfoNCE, st_simloss.hip): s = acc * scale; target column of row r is row_offset + r.
   //  LSE: partial[row*gridDim.y + blockIdx.y] = (running max, sum exp(s - max), s[target] or 0, 0)
-  //  DS : out[row*ldo + col] = g[row] * (exp(s - lse[row]) - [col == target]) * scale
+  //  DS : out[row*ldo + col] = g[row] * (exp(s - lse[row]) - [col == target]) * scale;  g == null: the bare exp(..) - [..]
+  //  DST: the transposed block (rows = keys, columns = queries): out[row*ldo + col] = exp(s - lse[col]) - [row == row_offset + col]
   float scale;
   int row_offset;
   const float* lse;

@@ -221,11 +221,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
             t.m1 = fmaxf(t.m1, v);
           } else if (EPI == EPI_LSE) {
             if (colok) {
+              // online log-sum-exp with ONE exponential per logit: e = exp(-|s - m|) rescales the sum (s > m) or is the
+              // new term (s <= m)
               const float sv = v * a.scale;
               Lse& u = run[mi][r];
-              const float mn = fmaxf(u.m, sv);
-              u.l = u.l * expf(u.m - mn) + expf(sv - mn);
-              u.m = mn;
+              const float d = sv - u.m;
+              const float e = H ? __expf(-fabsf(d)) : expf(-fabsf(d));
+              u.l = d > 0.0f ? fmaf(u.l, e, 1.0f) : u.l + e;
+              u.m = fmaxf(u.m, sv);
               if (col == a.row_offset + row) tgt[mi][r] = sv;
             }
           } else if (row < n && colok) {
@@ -237,8 +240,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
               ST_STORE(&a.out[(size_t)row * a.ldo + col], v + pre[mi][r]);
             } else if (EPI == EPI_DS) {
               const float sv = v * a.scale;
-              const float pr = expf(sv - a.lse[row]) - (col == a.row_offset + row ? 1.0f : 0.0f);
-              a.out[(size_t)row * a.ldo + col] = a.g[row] * pr * a.scale;
+              const float x = sv - a.lse[row];
+              const float pr = (H ? __expf(x) : expf(x)) - (col == a.row_offset + row ? 1.0f : 0.0f);
+              a.out[(size_t)row * a.ldo + col] = a.g ? a.g[row] * pr * a.scale : pr;
+            } else if (EPI == EPI_DST) {
+              const float x = v * a.scale - a.lse[col];
+              a.out[(size_t)row * a.ldo + col] = (H ? __expf(x) : expf(x)) - (row == a.row_offset + col ? 1.0f : 0.0f);
             } else if (EPI == EPI_QKV) {
               if (col < 256) {
                 ST_STORE(&a.q[(size_t)row * 256 + col], v);

@@ -10,7 +10,9 @@
 #include "st_rowpanel.h"
 
 #define SL_SPLITS 4
-#define SL_CHUNK 1024
+#ifndef SL_CHUNK
+#define SL_CHUNK 2048
+#endif
 #define SL_KSPLIT 16
 
 // u = x / max(||x||, 1e-8), nrm = max(||x||, 1e-8); wave per row.  ut (optional) = u transposed [256, n]
@@ -50,23 +52,57 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(const float4* __restrict
 // dx = (du - (du . u) u) / nrm  (backward of x -> x / max(||x||, eps));  out = or += dx
 __global__ __launch_bounds__(256) void unit_rows_bwd_kernel(const float* __restrict__ du, const float* __restrict__ u,
                                                             const float* __restrict__ nrm, int n,
-                                                            float* __restrict__ dx, int accumulate) {
+                                                            float* __restrict__ dx, int accumulate,
+                                                            const float* __restrict__ rowscale) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const int lane = threadIdx.x & 63;
   const f32x4 g = *(const f32x4*)(du + (size_t)r * 256 + lane * 4);
   const f32x4 v = *(const f32x4*)(u + (size_t)r * 256 + lane * 4);
   const float d = wave_sum(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w);
-  f32x4 o = (g - d * v) / nrm[r];
+  f32x4 o = (g - d * v) * ((rowscale ? rowscale[r] : 1.0f) / nrm[r]);
   float* p = dx + (size_t)r * 256 + lane * 4;
   if (accumulate) o += *(const f32x4*)p;
   *(f32x4*)p = o;
 }
 
+// ut[c][r] = s[r] * u[r][c]  (rows scaled by g / tau, transposed: the B operand of d_ku = dS^T . (s * ou))
+__global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __restrict__ u, const float* __restrict__ g, float scale,
+                                                              int n, float* __restrict__ ut, float* __restrict__ rowscale) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float sc = g[r] * scale;
+  const f32x4 v = *(const f32x4*)(u + (size_t)r * 256 + lane * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ut[(size_t)(lane * 4 + j) * n + r] = sc * v[j];
+  if (lane == 0) rowscale[r] = sc;
+}
+
+// Operand format of the similarity GEMMs (ST_GEMM_*).  F16X3 (default): unit rows lie in [-1, 1] and dS in [-1, 1], the
+// ideal domain of the hi + lo split (f32-grade: ~2^-22 per term), and every product of the block runs on the f16 MFMA.
+static int g_sl_format = ST_GEMM_F16X3;
+extern "C" int st_simloss_format(int gemm_format) {
+  const int prev = g_sl_format;
+  if (gemm_format == ST_GEMM_F32 || gemm_format == ST_GEMM_F16X3) g_sl_format = gemm_format;
+  return prev;
+}
+static int sl_pack(const float* W, int N, int K, float* out, hipStream_t st) {
+  if (g_sl_format == ST_GEMM_F16X3) {
+    const size_t total = (size_t)((N + 31) / 32) * (K >> 4) * 64;
+    hipLaunchKernelGGL(pack_weight_h_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, out);
+  } else {
+    const size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
+    hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, out);
+  }
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
 static inline size_t sl_align(size_t v) { return (v + 255) / 256 * 256; }
 
 struct SlWs {
-  float *ou, *ku, *kup, *kut, *kutp, *on, *kn, *dou, *dku, *ds, *slab;
+  float *ou, *ku, *kup, *kut, *kutp, *on, *kn, *dou, *dku, *ds, *slab, *oup, *oust, *oustp, *rs;
   float4* partial;
   size_t total;
 };
@@ -89,7 +125,12 @@ static SlWs sl_carve(int Bq, int Bk, char* base) {
   w.dou = (float*)take((size_t)Bq * 1024);
   w.dku = (float*)take((size_t)Bk * 1024);
   w.partial = (float4*)take((size_t)Bq * SL_SPLITS * 16);
-  w.ds = (float*)take((size_t)(Bq < SL_CHUNK ? Bq : SL_CHUNK) * Bk * 4);
+  const size_t big = Bq > Bk ? Bq : Bk;
+  w.ds = (float*)take((size_t)SL_CHUNK * big * 4);
+  w.oup = (float*)take(rp_packed_floats(Bq, 256) * 4);
+  w.oust = (float*)take((size_t)Bq * 1024);
+  w.oustp = (float*)take((size_t)Bq * 1024);
+  w.rs = (float*)take((size_t)Bq * 4);
   w.total = off;
   return w;
 }
@@ -122,9 +163,9 @@ extern "C" int st_simloss_fwd(const float* ori, const float* like, int Bq, int B
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, (float*)nullptr);
   ST_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((rp_packed_floats(Bk, 256) / 4 + 255) / 256)), dim3(256), 0, st, w.ku, Bk, 256, w.kup);
-  ST_LAUNCH_CHECK();
+  ST_TRY(sl_pack(w.ku, Bk, 256, w.kup, st));
   GemmArgs g = {};
+  g.fmt = g_sl_format;
   g.X = w.ou; g.n_host = Bq; g.W = w.kup; g.N = Bk; g.scale = 1.0f / tau; g.row_offset = row_offset; g.partial = w.partial;
   ST_TRY(launch_rp<EPI_LSE>(g, Bq, SL_SPLITS, st));
   hipLaunchKernelGGL(lse_merge_kernel, dim3((Bq + 255) / 256), dim3(256), 0, st, w.partial, SL_SPLITS, Bq, loss, lse);
@@ -143,6 +184,63 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, w.kut);
   ST_LAUNCH_CHECK();
+  if (g_sl_format == ST_GEMM_F16X3 && Bq % 256 == 0 && Bk % 256 == 0) {
+    // Every product on the row-panel kernels in the split format.  The gradient weights g / tau leave the matrices:
+    // dS' = exp(s - lse) - [target] in [-1, 1] is what gets split into f16 hi + lo (g * dS ~ 1e-8 would sit below the
+    // f16 range); d_ou rows are scaled afterwards, d_ku contracts against ou rows that carry the scale.
+    //   d_ou = (dS' . ku) * s_i          dS' [chunk of queries, Bk]  (EPI_DS)  then K = Bk chunked GEMM
+    //   d_ku = dS'^T . (s_i ou_i)        dS'^T [chunk of keys, Bq]   (EPI_DST: the transposed block straight from ku . ou^T)
+    const float scale = 1.0f / tau;
+    hipLaunchKernelGGL(scale_transpose_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, w.ou, g, scale, Bq, w.oust, w.rs);
+    ST_LAUNCH_CHECK();
+    ST_TRY(sl_pack(w.ku, Bk, 256, w.kup, st));
+    ST_TRY(sl_pack(w.ou, Bq, 256, w.oup, st));
+    ST_TRY(sl_pack(w.kut, 256, Bk, w.kutp, st));
+    ST_TRY(sl_pack(w.oust, 256, Bq, w.oustp, st));
+    auto chunked = [&](const float* Xrows, int n_rows, const float* Wp, int Ncols, int epi_t, const float* Wt_p, float* dst,
+                       int row_off0) -> int {
+      for (int r0 = 0; r0 < n_rows; r0 += SL_CHUNK) {
+        const int rows = (n_rows - r0 < SL_CHUNK) ? n_rows - r0 : SL_CHUNK;
+        GemmArgs a = {};
+        a.fmt = ST_GEMM_F16X3;
+        a.X = Xrows + (size_t)r0 * 256; a.n_host = rows; a.W = Wp; a.N = Ncols; a.scale = scale; a.out = w.ds; a.ldo = Ncols;
+        a.lse = epi_t ? lse : lse + r0;
+        // DS: target column of row r is row_offset + r0 + r;  DST: row (key) r0 + r is the target of query column c iff r0 + r == row_offset + c
+        a.row_offset = epi_t ? row_offset - r0 : row_offset + r0;
+        // column splits: enough workgroups to fill the chip (a chunk is only rows / 64 panels), at least 2 blocks per wave
+        const int panels = (rows + 63) / 64, nblk = (Ncols + 31) / 32;
+        int sp = (Ncols + 1023) / 1024;
+        while (sp * panels < 512 && sp * 2 * 8 <= nblk) sp *= 2;
+        if (epi_t)
+          ST_TRY(launch_rp<EPI_DST>(a, rows, sp, st));
+        else
+          ST_TRY(launch_rp<EPI_DS>(a, rows, sp, st));
+        GemmArgs b = {};
+        b.fmt = ST_GEMM_F16X3;
+        b.X = w.ds; b.n_host = rows; b.K = Ncols; b.W = Wt_p; b.N = 256; b.ldo = 256;
+        const int nchunk = Ncols >> 8;
+        int ks = SL_KSPLIT < nchunk ? SL_KSPLIT : nchunk;
+        while (ks > 1 && ((rows + 63) / 64) * ks > 1024) ks >>= 1;
+        b.out = ks > 1 ? w.slab : dst + (size_t)r0 * 256;
+        ST_TRY(launch_rp_kchunk<EPI_BIAS>(b, rows, st, ks));
+        if (ks > 1) {
+          const size_t n4 = (size_t)rows * 64;
+          hipLaunchKernelGGL(slab_reduce_kernel<0>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.slab, ks, n4,
+                             dst + (size_t)r0 * 256, n4);
+          ST_LAUNCH_CHECK();
+        }
+      }
+      return ST_OK;
+    };
+    ST_TRY(chunked(w.ou, Bq, w.kup, Bk, 0, w.kutp, w.dou, 0));
+    ST_TRY(chunked(w.ku, Bk, w.oup, Bq, 1, w.oustp, w.dku, 0));
+    hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, w.dou, w.ou, w.on, Bq, d_ori, 0, (const float*)w.rs);
+    hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, w.dku, w.ku, w.kn, Bk, d_like, 1, (const float*)nullptr);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
+  // exact-f32 form (ST_GEMM_F32, or sizes that are not multiples of 256): f32 row-panel kernels for dS and d_ou, the
+  // generic transposed-operand f32 kernel for d_ku
   hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((rp_packed_floats(Bk, 256) / 4 + 255) / 256)), dim3(256), 0, st, w.ku, Bk, 256, w.kup);
   ST_LAUNCH_CHECK();
   const bool splitk = (Bk % 256 == 0);   // d_ou = dS . ku on the row-panel kernel, K = Bk split over workgroups
@@ -183,8 +281,8 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
     c.out = w.dku; c.ldo = 256; c.resid = w.dku;
     ST_TRY((launch_kloop<EPI_RESID, true, true>(c, Bk, st)));
   }
-  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, w.dou, w.ou, w.on, Bq, d_ori, 0);
-  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, w.dku, w.ku, w.kn, Bk, d_like, 1);
+  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, w.dou, w.ou, w.on, Bq, d_ori, 0, (const float*)nullptr);
+  hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, w.dku, w.ku, w.kn, Bk, d_like, 1, (const float*)nullptr);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

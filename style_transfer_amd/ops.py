@@ -170,6 +170,12 @@ def accept_changes(new_ids, acc_ids, vocab, n_changes, changed, active, max_chan
                                   _p(rec_ids), _p(confirm_ids), _stream()), "st_accept_changes")
 
 
+def simloss_format(gemm_format):
+    """operand format of the similarity products ("f16x3" default, "f32" exact); returns the previous one"""
+    prev = lib().st_simloss_format(_fmt(gemm_format))
+    return {v: k for k, v in _lib.GEMM_FORMATS.items()}[prev]
+
+
 def simloss_fwd(ori, like, tau=0.1, row_offset=0):
     """-> (loss [Bq], lse [Bq]) of the in-batch InfoNCE block (siamese_contrastive.py:1060-1069)."""
     _f32(ori); _f32(like)

@@ -254,7 +254,16 @@ def test_accept_changes(dev):
     assert np.array_equal(rec.cpu().numpy()[:5], a[:5])
 
 
-def test_simloss_golden_b128(dev):
+@pytest.fixture(params=["f16x3", "f32"])
+def sl_fmt(request):
+    """both operand formats of the similarity products meet the same tolerances"""
+    from style_transfer_amd import ops
+    prev = ops.simloss_format(request.param)
+    yield request.param
+    ops.simloss_format(prev)
+
+
+def test_simloss_golden_b128(dev, sl_fmt):
     """reference torch code of siamese_contrastive.py:1060-1069 at B = 128 (fixture simloss_b128.npz)"""
     from style_transfer_amd import ops
     g = gold("simloss_b128.npz")
@@ -274,8 +283,8 @@ def test_simloss_golden_b128(dev):
     assert relerr(d_ori, g["d_ori"]) < 1e-3
 
 
-@pytest.mark.parametrize("Bq,Bk,off", [(64, 320, 32), (1088, 1088, 0), (96, 2048, 1900)])
-def test_simloss_vs_oracle(dev, Bq, Bk, off):
+@pytest.mark.parametrize("Bq,Bk,off", [(64, 320, 32), (1088, 1088, 0), (96, 2048, 1900), (256, 1536, 1024), (1280, 1280, 0)])
+def test_simloss_vs_oracle(dev, Bq, Bk, off, sl_fmt):
     from style_transfer_amd import ops
     rng = np.random.default_rng(Bq)
     ori = (rng.random((Bq, 256)) * 10).astype(np.float32)
@@ -292,7 +301,7 @@ def test_simloss_vs_oracle(dev, Bq, Bk, off):
     assert relerr(dl.cpu().numpy(), dl_ref) < 1e-3
 
 
-def test_simloss_full_size_b8192(dev):
+def test_simloss_full_size_b8192(dev, sl_fmt):
     """BASELINE config 5 at its full size (B = 8192 rows x 8192 in-batch negatives): the [B,B] matrix is never
     materialised by the kernels; checked against a chunked float64 torch evaluation of the same formula
     (siamese_contrastive.py:1060-1069) and through the size-independent identities sum_j dS[i,j] = 0
