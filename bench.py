@@ -91,6 +91,10 @@ def parse_args(argv=None):
                     help="skip the short extra runs reported in config (exact-f32 format, fixed 59 steps, log decodes on, end to end)")
     ap.add_argument("--gemm-format", default="f16x3", choices=["f16x3", "f32"],
                     help="operand format of the AE weight GEMMs: 3-product f16 split (f32-grade results) or exact f32 MFMA")
+    ap.add_argument("--config", default="attack", choices=["attack", "simloss"],
+                    help="attack: the headline workload (BASELINE configs 1-4); simloss: BASELINE config 5, one contrastive constraint-loss "
+                         "step (11 views, forward + backward) with B = --simloss-batch GLOBAL in-batch negatives, rows sharded over the GPUs")
+    ap.add_argument("--simloss-batch", type=int, default=8192)
     ap.add_argument("--dry-run", action="store_true",
                     help="control-flow rehearsal without a GPU: launch, rendezvous (gloo), barrier, max-over-ranks timing and the "
                          "one JSON line; no kernel runs and `value` is null")
@@ -129,11 +133,121 @@ def algorithmic_flops(ae, B_total, units, enc_rows, enc_sq, kp, kn, work):
     return dict(decode=decode, encode=encode, scorer=scorer, total=decode + encode + scorer)
 
 
+def simloss_cpu_baseline(views):
+    """oracle/st_oracle.py simloss + simloss_grads (numpy, f64 accumulate) on a B = 2048 block, one view; reported per
+    8192-sentence 11-view step by the flop ratio (the work is exactly quadratic in B and linear in views)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import st_oracle as O
+    rng = np.random.default_rng(5)
+    Bs = 2048
+    ori, like = rng.random((Bs, 256), np.float32) * 10, rng.random((Bs, 256), np.float32) * 10
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 10.0:
+        _, lse = O.simloss(ori, like, 0.1, 0)
+        O.simloss_grads(ori, like, np.full(Bs, 1.0 / Bs), 0.1, 0)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    return {"value": 2048 / (dt * views) / 4.0, "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": "oracle simloss + simloss_grads, B = 2048, one view, %d repeats of %.3f s; value scaled to B = 8192 and 11 views "
+                      "(work per sentence 4x that of the sample)" % (n, dt)}
+
+
+def simloss_main(a):
+    """BASELINE config 5: the in-batch contrastive loss block of train_ae_model_constraint (siamese_contrastive.py:1055-1072)
+    with B global negatives; every rank owns B / N rows (strong scaling: the global batch is fixed) and runs
+    contrastive.constraint_loss_and_grads: one all_gather of the views' latents, its [B/N, B] row block of every view through
+    st_simloss_fwd / st_simloss_bwd, one reduce-scatter of d_like."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    from style_transfer_amd import ops
+    from style_transfer_amd.contrastive import constraint_loss_and_grads
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    B, views, tau = a.simloss_batch, 11, 0.1
+    assert B % (32 * world) == 0
+    b = B // world
+    ops.simloss_format(a.gemm_format)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_run = a.warmup + a.steps
+    # latents of a trained encoder are O(1..10) per coordinate with a common offset (tests/golden/simloss_b128.npz): rand * 10
+    oris = [torch.rand(b, 256, device=dev, generator=gen) * 10 for _ in range(n_run)]
+    likes = [torch.rand(views, b, 256, device=dev, generator=gen) * 10 for _ in range(n_run)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(a.warmup):
+        constraint_loss_and_grads(oris[k], likes[k], tau)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.warmup, n_run):
+        loss, d_ori, d_like = constraint_loss_and_grads(oris[k], likes[k], tau)
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    sec = float(tt.item()) / a.steps
+    # kernels only (no collectives, no host .item()): HIP events on the current stream around the 11 views' launches
+    like_all = torch.rand(views, B, 256, device=dev, generator=gen) * 10
+    g = torch.full((b,), 1.0 / (views * B), device=dev)
+    d_like = torch.zeros_like(like_all)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for v in range(views):
+        _, lse = ops.simloss_fwd(oris[0], like_all[v], tau, rank * b)
+        ops.simloss_bwd(oris[0], like_all[v], lse, g, tau, rank * b, d_like[v])
+    e1.record()
+    torch.cuda.synchronize()
+    ksec = e0.elapsed_time(e1) * 1e-3
+    flops = views * 4 * 2.0 * b * B * 256            # per rank: S = ou.ku^T forward, S again + dS.ku + dS^T.ou backward
+    if rank == 0:
+        out = {"metric": "contrastive constraint-loss sentences/sec (in-batch InfoNCE, global negatives, forward + backward)",
+               "value": B / sec, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32 (split-f16 MFMA operands, f32 accumulate)" if a.gemm_format == "f16x3" else "f32",
+               "data": "synthetic",
+               "config": {"workload": "BASELINE config 5: %d views x [%d, %d] similarity block per GPU, width 256, tau %.1f; all_gather of the "
+                                      "views + reduce-scatter of d_like when N > 1" % (views, b, B, tau),
+                          "global_batch": B, "rows_per_gpu": b, "views": views, "gemm_format": a.gemm_format,
+                          "kernels_only_ms": ksec * 1e3},
+               "roofline": {"bound": "mfma", "achieved": flops / ksec / 1e12,
+                            "peak": F16_MFMA_PEAK_TFLOPS if a.gemm_format == "f16x3" else F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flops / ksec / 1e12 / (F16_MFMA_PEAK_TFLOPS if a.gemm_format == "f16x3" else F32_MFMA_PEAK_TFLOPS),
+                            "traffic": None,
+                            "note": "algorithmic flops = views x 4 GEMM-sized products x 2 b B 256; the f16x3 form issues 3 MFMA products "
+                                    "per algorithmic one and recomputes S once more for the transposed block (15 issued per 4 algorithmic)"}}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = simloss_cpu_baseline(views)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse_args(argv)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a, argv)
+    if a.config == "simloss" and not a.dry_run:
+        return simloss_main(a)
 
     import torch
     import torch.distributed as dist

@@ -13,7 +13,7 @@ each view (one fused all_gather of all views: small, latency-bound messages over
 [b, B] row block with complete rows — the softmax needs no further exchange — and in the backward pass
 reduce-scatters d_like (every rank holds a partial sum for ALL B rows).  The scalar loss is
 all-reduced.  `fwd`/`bwd` default to the HIP kernels (ops.simloss_fwd / ops.simloss_bwd); the CPU test
-injects the oracle to check the sharding arithmetic under gloo.
+injects the oracle (and a gloo stand-in for reduce-scatter) to check the sharding arithmetic.
 """
 import torch
 import torch.distributed as dist
@@ -23,10 +23,12 @@ def _world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
-def constraint_loss_and_grads(ori, like_views, tau=0.1, fwd=None, bwd=None):
+def constraint_loss_and_grads(ori, like_views, tau=0.1, fwd=None, bwd=None, reduce_scatter=None):
     """ori [b,256] (this rank's rows), like_views [n_views,b,256] (this rank's rows of every view).
     -> (loss: python float = mean over views and ALL rows, d_ori [b,256], d_like_views [n_views,b,256])
-    Gradients are those of the global mean loss, as `constraint_loss.backward()` would give."""
+    Gradients are those of the global mean loss, as `constraint_loss.backward()` would give.
+    `reduce_scatter(out_flat, in_flat)` defaults to RCCL's reduce_scatter_tensor; a backend without one (the
+    gloo CPU test) injects its own, as it injects fwd/bwd."""
     if fwd is None or bwd is None:
         from . import ops
         fwd = fwd or ops.simloss_fwd
@@ -54,11 +56,7 @@ def constraint_loss_and_grads(ori, like_views, tau=0.1, fwd=None, bwd=None):
         d_like = torch.empty(n_views, b, d, dtype=like_views.dtype, device=like_views.device)
         # reduce-scatter d_like over the row blocks: rank r keeps rows [r*b, (r+1)*b) of every view
         send = d_like_all.view(n_views, world, b, d).permute(1, 0, 2, 3).contiguous()
-        if dist.get_backend() == "gloo":    # gloo has no reduce_scatter: all_reduce + slice (test path only)
-            dist.all_reduce(send)
-            d_like.copy_(send[rank])
-        else:
-            dist.reduce_scatter_tensor(d_like.view(-1), send.view(-1))
+        (reduce_scatter or dist.reduce_scatter_tensor)(d_like.view(-1), send.view(-1))
     else:
         d_like = d_like_all
     return float(loss_sum.item()) / (n_views * B), d_ori, d_like
