@@ -21,6 +21,7 @@
 #include "st_gemm.h"
 
 #include <stdlib.h>
+#include <algorithm>
 
 // streaming outputs (written once, read by a later kernel): nontemporal stores keep them from evicting
 // the L2-resident weights
@@ -50,6 +51,18 @@ __device__ __forceinline__ void panel_store4(float* row, int c4, f32x4 v, int* f
   } else {
     *(f32x4*)(row + c4 * 4) = v;
   }
+}
+
+// The same (f16x3 only) without the branch: the range violation is OR-ed into `bad`, which the caller reports once at its
+// end.  A branch per call keeps the scheduler from interleaving the independent rows of an unrolled loop.
+__device__ __forceinline__ void panel_store4_nb(float* row, int c4, f32x4 v, int& bad) {
+  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  bad |= !(m <= 65504.0f);
+  h4 hi, lo;
+  split_f16(v, hi, lo);
+  _Float16* ph = (_Float16*)row;
+  *(h4*)(ph + c4 * 4) = hi;
+  *(h4*)(ph + 256 + c4 * 4) = lo;
 }
 
 template <int EPI, int NW = 4, bool H = false>
@@ -1134,7 +1147,7 @@ static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
 // as packed halves (ds_write_b64) in exactly the layout the FFN2 A fragments are read from.
 // HBM traffic per row: att + x in, x out (3 KiB) instead of 13 KiB for the unfused chain.
 // ------------------------------------------------------------------------------------------------
-#define RP_TAIL_LDS (2 * 64 * ST_LDA * 4)
+#define RP_TAIL_LDS ((2 * 64 * ST_LDA + 64) * 4)  /* two panels + the cross-attention index of the next panel's rows */
 #define RP_TAIL_MIN_ROWS 4096  /* below this the unfused kernels (column splits) fill the chip better */
 #define RP_TAIL_MMA6(ACC0, ACC1, A0H, A0L, A1H, A1L, BH, BL) \
   ACC0 = mfma16h(A0H, BH, ACC0);                             \
@@ -1146,7 +1159,7 @@ static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
 
 #ifdef ST_TAIL_STAMPS
 __device__ unsigned long long g_tail_stamps[64];
-#define TSTAMP(i) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_tail_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#define TSTAMP(i) do { if (blockIdx.x == 100 && threadIdx.x == 0) g_tail_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TSTAMP(i)
 #endif
@@ -1158,13 +1171,19 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   extern __shared__ __align__(16) float smem[];
   float* P1 = smem;
   float* P2 = smem + 64 * ST_LDA;
+  int* sIdx = (int*)(smem + 2 * 64 * ST_LDA);
   const int n = a.n_dev ? *a.n_dev : a.n_host;
-  const int m0 = blockIdx.x * 64;
+  // PERSISTENT over panels (grid = one workgroup per CU): panel p + gridDim.x of this workgroup follows panel p, and its
+  // attention panel, residual rows and cross-attention constants are requested BEFORE the last FFN2 pass of panel p, so
+  // the entry latency of a panel (10.7 k of 93.7 k cycles in the one-panel-per-workgroup form, plus ~7 us of workgroup
+  // turnaround per round) is paid once per workgroup.  A grid of one workgroup per panel runs the loop once (kbench A/B).
+  const int mstride = gridDim.x * 64;
+  int m0 = blockIdx.x * 64;
   if (m0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int col = wave * 32 + l31;  // this lane's output column (O-projection and FFN2)
+  int half = lane >> 5, l31 = lane & 31;
+  int col = wave * 32 + l31;  // this lane's output column (O-projection and FFN2)
   const int nchunk = a.d_ff >> 8;
   TSTAMP(31);
 
@@ -1179,46 +1198,89 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
     }
   };
 
+  int bad = 0;    // an operand left the f16 range (or is NaN): reported once at the end
+  f32x4 attr[8];  // this thread's share of an attention panel on its way from HBM to P1
+  auto att_load = [&](int mb) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int f = tid + i * 512;
-    const int r = f >> 6, c4 = f & 63;
-    panel_store4<true>(P1 + r * ST_LDA, c4, *(const f32x4*)(a.att + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4), a.range_flag);
-  }
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + i * 512;
+      attr[i] = *(const f32x4*)(a.att + (size_t)min(mb + (f >> 6), n - 1) * 256 + (f & 63) * 4);
+    }
+  };
+  auto att_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + i * 512;
+      panel_store4_nb(P1 + (f >> 6) * ST_LDA, f & 63, attr[i], bad);
+    }
+  };
+  // The residual (+ cross-attention constant: a dependent gather through idx, staged in LDS one phase earlier) joins the
+  // accumulators AFTER the O-projection pass, so only the attention panel's latency stands before the first MFMA.
+  f32x16 ax0, ax1, px0, px1, pc0, pc1;
+  auto idx_stage = [&](int mb) {
+    if (a.cconst && tid < 64) sIdx[tid] = a.idx[min(mb + tid, n - 1)];
+  };
+  auto resid_load = [&](int mb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int r0 = mfma32_row(r, lane);
+      const int row0 = min(mb + r0, n - 1), row1 = min(mb + 32 + r0, n - 1);
+      px0[r] = a.x[(size_t)row0 * 256 + col];
+      px1[r] = a.x[(size_t)row1 * 256 + col];
+    }
+    if (a.cconst) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int r0 = mfma32_row(r, lane);
+        pc0[r] = a.cconst[(size_t)sIdx[r0] * 256 + col];
+        pc1[r] = a.cconst[(size_t)sIdx[32 + r0] * 256 + col];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pc0[r] = pc1[r] = 0.0f;
+    }
+  };
+  att_load(m0);
+  idx_stage(m0);
   // parameters used after barriers are fetched now (their latency would otherwise be exposed there)
   const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
   const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
   const float b2v = a.b2[col];
+  const float bov = a.bo[col];
   f32x4 b1n[4];  // FFN1 bias of this lane's 16 hidden units in the coming chunk (transposed tile: 8g + 4*half + q)
   auto b1_fetch = [&](int c) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) b1n[g] = *(const f32x4*)(a.b1 + (c * 8 + wave) * 32 + 8 * g + 4 * half);
   };
-  // ---- O-projection; accumulators start from bias + residual (+ constant) ----
+  att_store();
+  __syncthreads();  // sIdx of the first panel
+  resid_load(m0);
+  bool first = true;
+  for (;;) {
+  // The lane coordinates are re-derived from an opaque copy of the thread index in every iteration: otherwise the
+  // compiler hoists ~120 registers of loop-invariant addresses out of the panel loop and spills them.
+  TSTAMP(35);
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
+  half = lane >> 5;
+  l31 = lane & 31;
+  col = wave * 32 + l31;
+  // ---- O-projection; accumulators start from the bias ----
   const f32x4* Wo = (const f32x4*)a.wo + (size_t)wave * 16 * 128 + lane;
-  ring_fill(Wo);
-  // The residual (+ cross-attention constant: a dependent gather through idx) is requested now and joins the
-  // accumulators AFTER the O-projection pass, so only the attention panel's latency stands before the first MFMA.
-  f32x16 ax0, ax1, px0, px1, pc0, pc1;
-  {
-    const float bv = a.bo[col];
+  auto W1p = [&](int c) { return (const f32x4*)a.w1 + (size_t)(c * 8 + wave) * 16 * 128 + lane; };                  // hidden block 8c + wave
+  auto W2p = [&](int c) { return (const f32x4*)a.w2 + ((size_t)wave * (a.d_ff >> 4) + c * 16) * 128 + lane; };  // k-steps 16c .. 16c+15 of output block `wave`
+  if (first) ring_fill(Wo);
+  first = false;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row0 = min(m0 + mfma32_row(r, lane), n - 1), row1 = min(m0 + 32 + mfma32_row(r, lane), n - 1);
-      px0[r] = a.x[(size_t)row0 * 256 + col];
-      px1[r] = a.x[(size_t)row1 * 256 + col];
-      pc0[r] = a.cconst ? a.cconst[(size_t)a.idx[row0] * 256 + col] : 0.0f;
-      pc1[r] = a.cconst ? a.cconst[(size_t)a.idx[row1] * 256 + col] : 0.0f;
-      ax0[r] = ax1[r] = bv;
-    }
-  }
+  for (int r = 0; r < 16; ++r) ax0[r] = ax1[r] = bov;
   TSTAMP(0);
   __syncthreads();
   TSTAMP(1);
   const float* A1 = P1 + l31 * ST_LDA + 4 * half;  // fragment base in P1 (rows l31 and l31 + 32)
   const float* A2 = P2 + l31 * ST_LDA + 4 * half;
   // one 16-step pass: standard orientation (panel rows x W columns) or transposed (W rows x panel rows)
-  auto pass = [&](const float* Ab, const f32x4* Wb, f32x16& c0, f32x16& c1, bool transposed) {
+  // (the W ring never drains: the last RG steps of a pass request the first RG steps of the NEXT pass, Wn)
+  auto pass = [&](const float* Ab, const f32x4* Wb, const f32x4* Wn, f32x16& c0, f32x16& c1, bool transposed) {
     f32x4 an[4];  // A fragments of the next k-step (requested one step ahead)
     an[0] = *(const f32x4*)(Ab);
     an[1] = *(const f32x4*)(Ab + 128);
@@ -1230,9 +1292,12 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
       for (int j = 0; j < RG; ++j) {
         const int kg = g0 + j;
         const h8 bh = as_h8(rh[j]), bl = as_h8(rl[j]);
-        if (kg + RG < 16) {  // static after unrolling: the last RG steps of a pass fetch nothing (ring_fill follows)
+        if (kg + RG < 16) {  // static after unrolling
           rh[j] = Wb[(size_t)(kg + RG) * 128];
           rl[j] = Wb[(size_t)(kg + RG) * 128 + 64];
+        } else {
+          rh[j] = Wn[(size_t)(kg + RG - 16) * 128];
+          rl[j] = Wn[(size_t)(kg + RG - 16) * 128 + 64];
         }
         const h8 a0h = as_h8(an[0]), a0l = as_h8(an[1]), a1h = as_h8(an[2]), a1l = as_h8(an[3]);
         if (kg + 1 < 16) {
@@ -1257,7 +1322,7 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
       }
     }
   };
-  pass(A1, Wo, ax0, ax1, false);
+  pass(A1, Wo, W1p(0), ax0, ax1, false);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     ax0[r] += px0[r] + pc0[r];
@@ -1265,6 +1330,7 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   }
   TSTAMP(2);
   b1_fetch(0);
+  if (m0 + mstride < n) idx_stage(m0 + mstride);  // read by resid_load before the last FFN2 pass, many barriers from here
   __syncthreads();  // every wave is done reading the attention panel
   TSTAMP(3);
   // ---- x1 -> P1 (f32), LayerNorm + split in place ----
@@ -1273,16 +1339,14 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
     P1[(mfma32_row(r, lane)) * ST_LDA + col] = ax0[r];
     P1[(32 + mfma32_row(r, lane)) * ST_LDA + col] = ax1[r];
   }
-  const f32x4* W1b = (const f32x4*)a.w1 + (size_t)wave * 16 * 128 + lane;  // hidden block (chunk*8 + wave)
-  ring_fill(W1b);
   TSTAMP(32);
   __syncthreads();
   TSTAMP(33);
   {
-#pragma unroll 4
+#pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       float* row = P1 + (wave * 8 + rr) * ST_LDA;
-      panel_store4<true>(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), a.range_flag);
+      panel_store4_nb(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
     }
   }
   {
@@ -1296,7 +1360,6 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   __syncthreads();
   _Float16* H2 = (_Float16*)P2;
   TSTAMP(4);
-  int bad = 0;
   // ReLU + f16 split of one accumulator group (4 consecutive hidden units of one panel row) -> hidden chunk in P2
   auto epi_unit = [&](const f32x16& acc, int g, int rowbase) {
     f32x4 v;
@@ -1312,7 +1375,7 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   };
   // FFN1 pass of the NEXT chunk (transposed, into c0 / c1) with the conversion of the CURRENT chunk's accumulators
   // (o0 / o1) spread over its k-steps: one basic block, so the VALU / LDS-store work runs in the MFMAs' shadow
-  auto pass_epi = [&](const float* Ab, const f32x4* Wb, f32x16& c0, f32x16& c1, const f32x16& o0, const f32x16& o1) {
+  auto pass_epi = [&](const float* Ab, const f32x4* Wb, const f32x4* Wn, f32x16& c0, f32x16& c1, const f32x16& o0, const f32x16& o1) {
     f32x4 an[4];  // A fragments of the next k-step, requested one step ahead (LDS latency ~ one step)
     an[0] = *(const f32x4*)(Ab);
     an[1] = *(const f32x4*)(Ab + 128);
@@ -1325,6 +1388,9 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
       if (kg + RG < 16) {
         rh[j] = Wb[(size_t)(kg + RG) * 128];
         rl[j] = Wb[(size_t)(kg + RG) * 128 + 64];
+      } else {
+        rh[j] = Wn[(size_t)(kg + RG - 16) * 128];
+        rl[j] = Wn[(size_t)(kg + RG - 16) * 128 + 64];
       }
       const h8 a0h = as_h8(an[0]), a0l = as_h8(an[1]), a1h = as_h8(an[2]), a1l = as_h8(an[3]);
       if (kg + 1 < 16) {
@@ -1365,41 +1431,43 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
   ah_init(ah0, ah1);
   if (nchunk > 1) b1_fetch(1);  // consumed one chunk later
   TSTAMP(5);
-  pass(A1, W1b, ah0, ah1, true);
+  pass(A1, W1p(0), nchunk > 1 ? W1p(1) : W2p(0), ah0, ah1, true);
   TSTAMP(6);
-  for (int c = 0; c < nchunk; ++c) {
-    const bool more = c + 1 < nchunk;
+  for (int c = 0; c + 1 < nchunk; ++c) {
     f32x16 an0, an1;
-    if (more) {
-      W1b = (const f32x4*)a.w1 + (size_t)((c + 1) * 8 + wave) * 16 * 128 + lane;
-      ring_fill(W1b);
-      ah_init(an0, an1);
-      if (c + 2 < nchunk) b1_fetch(c + 2);
-    }
+    ah_init(an0, an1);
+    if (c + 2 < nchunk) b1_fetch(c + 2);
     if (c > 0) __syncthreads();  // every wave is done reading the previous hidden chunk
     // ---- hidden chunk c -> P2, overlapped with FFN1 of chunk c + 1 ----
-    if (more) {
-      pass_epi(A1, W1b, an0, an1, ah0, ah1);
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        epi_unit(ah0, g, 0);
-        epi_unit(ah1, g, 32);
-      }
-    }
-    // this wave's W2 fragments for chunk c (k-steps 16c .. 16c+15 of output block `wave`)
-    const f32x4* W2b = (const f32x4*)a.w2 + ((size_t)wave * (a.d_ff >> 4) + c * 16) * 128 + lane;
-    ring_fill(W2b);
+    pass_epi(A1, W1p(c + 1), W2p(c), an0, an1, ah0, ah1);
     TSTAMP(7 + c * 5);
     __syncthreads();  // hidden chunk complete
     TSTAMP(8 + c * 5);
     // ---- FFN2 partial: x += h_c . W2[:, chunk]^T ----
-    pass(A2, W2b, ax0, ax1, false);
+    pass(A2, W2p(c), c + 2 < nchunk ? W1p(c + 2) : W2p(c + 1), ax0, ax1, false);
     TSTAMP(9 + c * 5);
-    if (more) {
-      ah0 = an0;
-      ah1 = an1;
+    ah0 = an0;
+    ah1 = an1;
+  }
+  {  // last chunk (peeled: the prefetch below must not be a conditional definition inside the chunk loop)
+    const int c = nchunk - 1;
+    // The next panel of this workgroup: its attention rows, residual rows and constants are requested here and arrive
+    // under the conversion, the two barriers and the last pass (memory returns in order: W fragments requested after
+    // these loads wait for them, so they are issued as early as the registers allow).  Unconditional, with clamped
+    // rows, so that the registers are plain definitions (a workgroup's last panel requests rows it never uses).
+    att_load(m0 + mstride);
+    resid_load(m0 + mstride);
+    if (c > 0) __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      epi_unit(ah0, g, 0);
+      epi_unit(ah1, g, 32);
     }
+    TSTAMP(7 + c * 5);
+    __syncthreads();  // hidden chunk complete
+    TSTAMP(8 + c * 5);
+    pass(A2, W2p(c), Wo, ax0, ax1, false);  // (a workgroup's last panel requests Wo once more and drops it)
+    TSTAMP(9 + c * 5);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1407,8 +1475,13 @@ __global__ __launch_bounds__(512, RP_TAIL_RING > 4 ? 1 : 2) void rp_layer_tail_k
     if (row0 < n) ST_STORE(&a.x[(size_t)row0 * 256 + col], ax0[r]);
     if (row1 < n) ST_STORE(&a.x[(size_t)row1 * 256 + col], ax1[r]);
   }
-  if (bad && a.range_flag) *a.range_flag = 1;
   TSTAMP(30);
+  m0 += mstride;
+  if (m0 >= n) break;
+  att_store();
+  TSTAMP(36);
+  }  // panels of this workgroup
+  if (bad && a.range_flag) *a.range_flag = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1663,6 +1736,17 @@ static int launch_layer_tail32(const OFArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
+static int rp_tail_persistent = 1;  // tools/kbench.cpp clears it for the one-panel-per-workgroup A/B
+static inline int st_cu_count() {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!cus[dev]) {
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cus[dev];
+}
 static int launch_layer_tail64(const OFArgs& a, int n_bound, hipStream_t st) {
   ST_ENSURE_LDS((rp_layer_tail_kernel<0>), RP_TAIL_LDS);
   if (n_bound <= 0) return ST_OK;
@@ -1670,7 +1754,9 @@ static int launch_layer_tail64(const OFArgs& a, int n_bound, hipStream_t st) {
     st_set_error("rp_layer_tail: needs the f16x3 format, d_ff %% 256 == 0 and w2/b2 (fmt=%d d_ff=%d)", a.fmt, a.d_ff);
     return ST_EINVAL;
   }
-  hipLaunchKernelGGL(rp_layer_tail_kernel<0>, dim3((n_bound + 63) / 64), dim3(512), RP_TAIL_LDS, st, a);
+  int grid = (n_bound + 63) / 64;
+  if (rp_tail_persistent) grid = std::min(grid, st_cu_count());  // 133 KiB of LDS: one workgroup per CU, each loops over its panels
+  hipLaunchKernelGGL(rp_layer_tail_kernel<0>, dim3(grid), dim3(512), RP_TAIL_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

@@ -158,6 +158,34 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_layer_tail64(a, n, st); });
     printf("layer tail n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * (256 + 2 * DFF) / t / 1e12);
     {
+      // A/B: persistent (one workgroup per CU, next panel prefetched) vs one workgroup per panel; bitwise comparison
+      double tp = 0, t1 = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        rp_tail_persistent = 1;
+        tp += timeit([&] { launch_layer_tail64(a, n, st); }, 5);
+        rp_tail_persistent = 0;
+        t1 += timeit([&] { launch_layer_tail64(a, n, st); }, 5);
+      }
+      printf("layer tail A/B n=%d: persistent %8.1f us   one panel per workgroup %8.1f us  (%.3f)\n", n, tp / 3 * 1e6, t1 / 3 * 1e6, tp / t1);
+      std::vector<float> x0((size_t)n * 256), yp(x0.size()), y1(x0.size());
+      float* xs = dev_rand((size_t)n * 256, 1.0f, 1);
+      CK(hipMemcpy(x0.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      OFArgs b = a;
+      b.x = xs;
+      rp_tail_persistent = 1;
+      launch_layer_tail64(b, n, st);
+      CK(hipMemcpy(yp.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(xs, x0.data(), x0.size() * 4, hipMemcpyHostToDevice));
+      rp_tail_persistent = 0;
+      launch_layer_tail64(b, n, st);
+      CK(hipMemcpy(y1.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      rp_tail_persistent = 1;
+      size_t diff = 0;
+      for (size_t i = 0; i < x0.size(); ++i) diff += memcmp(&yp[i], &y1[i], 4) != 0;
+      printf("  outputs: %zu of %zu elements differ bitwise\n", diff, x0.size());
+      CK(hipFree(xs));
+    }
+    if (getenv("KBENCH_TAIL32")) {
       // A/B: the 32-row / 4-wave form (two workgroups per CU), interleaved rounds, and a bitwise comparison of the outputs
       double t64 = 0, t32 = 0;
       for (int rep = 0; rep < 3; ++rep) {
@@ -185,10 +213,15 @@ int main(int argc, char** argv) {
       printf("  outputs: %zu of %zu elements differ bitwise, max |diff| %.3g, sample y64 %g y32 %g\n", diff, x0.size(), mx, y64[12345], y32[12345]);
     }
 #ifdef ST_TAIL_STAMPS
+    rp_tail_persistent = getenv("KBENCH_ONE_PANEL") ? 0 : 1;
+    launch_layer_tail64(a, n, st);
+    CK(hipDeviceSynchronize());
+    rp_tail_persistent = 1;
     unsigned long long hs[64];
     CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_tail_stamps), sizeof(hs)));
     const char* nm[] = {"entry -> loads issued", "wait + barrier0", "O-proj", "barrier1", "x1->LDS + LN + barriers", "bias init", "FFN1(0)"};
-    printf("  %-32s %8llu\n", nm[0], hs[0] - hs[31]);
+    printf("  (stamps of the LAST panel of workgroup 100)  kernel entry -> this panel's loop top %llu\n", hs[35] - hs[31]);
+    printf("  %-32s %8llu\n", "loop top -> ring + acc init", hs[0] - hs[35]);
     for (int i = 1; i <= 6; ++i) printf("  %-32s %8llu\n", nm[i], hs[i] - hs[i - 1]);
     printf("    of which: x1 -> LDS %llu, barrier %llu, LayerNorm %llu, barrier %llu\n", hs[32] - hs[3], hs[33] - hs[32], hs[34] - hs[33], hs[4] - hs[34]);
     for (int c = 0; c < 4; ++c) {
@@ -196,7 +229,7 @@ int main(int argc, char** argv) {
       printf("  chunk %d: FFN1(c+1) + convert(c) %6llu  barrier %6llu  FFN2 %6llu\n", c, hs[7 + 5 * c] - prev,
              hs[8 + 5 * c] - hs[7 + 5 * c], hs[9 + 5 * c] - hs[8 + 5 * c]);
     }
-    printf("  store %llu   total %llu\n", hs[30] - hs[24], hs[30] - hs[31]);
+    printf("  store %llu   panel total %llu   (previous panel: att_store after its store %llu)\n", hs[30] - hs[24], hs[30] - hs[35], hs[35] - hs[36]);
 #endif
   }
   CK(hipDeviceSynchronize());
