@@ -18,11 +18,17 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
   *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;
 }
 
-// Full (non-causal) self-attention inside each sentence of 17..64 tokens (amazon): block = sentence, wave = head.
-// Lane (g = lane >> 4, c = lane & 15) owns the keys j = g, g+4, ... (<= 16 of them) and dims 4c..4c+3 of the
-// head: its K and V slices stay in registers for all queries.  Per query: q.k partial sums are reduced over the
-// 16 lanes of a key group with DPP rotations, the softmax max / sum and the PV partial sums are combined over
-// the four groups with two xor-shuffles each.  qkv rows: [q | k | v] (768 floats).
+// Full (non-causal) self-attention inside each sentence of 17..64 tokens (amazon): block = sentence, wave = head, on
+// the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32), operands straight from the qkv rows in HBM / L2 (no LDS):
+//   S^T tile [32 keys x 32 queries] = K . Q^T : lane (l31, half) supplies row l31 of K (A operand) and of Q (B operand),
+//     dims half*32 .. half*32+31 of the head (8 coalesced float4 loads each); step kk contracts the dim pair
+//     {kk, 32 + kk}, so 32 steps cover the 64 dims.  The lane then holds 16 keys of ONE query (column l31): the
+//     softmax over keys is lane-local plus one exchange with lane ^ 32 for the maximum and one for the sum.
+//   O tile [32 queries x 32 dims] = P . V : the accumulator register r of the S^T tile IS the A operand of step r
+//     (keys {row(r, 0), row(r, 1)} of the tile), B = V[key][dim l31] is one dword load per step.
+// P is normalised before the product, as the reference multiplies softmax(scores) by V (model.py attention()).
+// qkv rows: [q | k | v] (768 floats).  The previous VALU kernel (keys in registers, one query at a time, 12 LDS-crossbar
+// shuffles per query) ran the amazon shape at 1.43 ms per launch; this one is bound by the qkv row traffic.
 template <bool FAST>  // as in enc_attn16_kernel below
 __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
                                                        float* __restrict__ out) {
@@ -30,50 +36,75 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
   const int r0 = off[s], len = off[s + 1] - r0;
   if (len <= 16 || len > 64) return;  // short sentences: enc_attn16_kernel
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  const float* base = qkv + (size_t)r0 * 768 + h * 64 + c * 4;
-  const int nk = (len - g + 3) >> 2;  // keys owned by this lane's group: j = g + 4t, t < nk
-  f32x4 kr[16], vr[16];
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* base = qkv + (size_t)r0 * 768 + h * 64;
+  const int nt = (len + 31) >> 5;  // 32-row tiles of queries and of keys: 1 or 2
+  f32x4 kf[2][8];
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
-    if (t < nk) {
-      kr[t] = *(const f32x4*)(base + (size_t)(g + 4 * t) * 768 + 256);
-      vr[t] = *(const f32x4*)(base + (size_t)(g + 4 * t) * 768 + 512);
+  for (int kj = 0; kj < 2; ++kj)
+    if (kj < nt) {
+      const float* kp = base + (size_t)min(kj * 32 + l31, len - 1) * 768 + 256 + half * 32;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kf[kj][c] = *(const f32x4*)(kp + c * 4);
     }
-  f32x4 qn = *(const f32x4*)base;
-  for (int i = 0; i < len; ++i) {
-    const f32x4 qv = qn;
-    if (i + 1 < len) qn = *(const f32x4*)(base + (size_t)(i + 1) * 768);
-    float sc[16];
+  for (int qi = 0; qi < nt; ++qi) {
+    f32x4 qf[8];
+    {
+      const float* qp = base + (size_t)min(qi * 32 + l31, len - 1) * 768 + half * 32;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) qf[c] = *(const f32x4*)(qp + c * 4);
+    }
+    f32x16 sacc[2];
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      sc[t] = -INFINITY;
-      if (t < nk) {
-        const float part = fmaf(qv.x, kr[t].x, fmaf(qv.y, kr[t].y, fmaf(qv.z, kr[t].z, qv.w * kr[t].w)));
-        sc[t] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
-        m = fmaxf(m, sc[t]);
+    for (int kj = 0; kj < 2; ++kj)
+      if (kj < nt) {
+        f32x16 acc = {0};
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = mfma32(kf[kj][c][e], qf[c][e], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kj * 32 + mfma32_row(r, lane);
+          acc[r] = key < len ? acc[r] * 0.125f : -INFINITY;  // / sqrt(d_k); keys beyond the sentence do not exist
+          m = fmaxf(m, acc[r]);
+        }
+        sacc[kj] = acc;
       }
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.0f;
-    f32x4 o4 = {0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (t < nk) {
-        const float e = FAST ? __expf(sc[t] - m) : expf(sc[t] - m);
-        sum += e;
-        o4 += e * vr[t];
+    for (int kj = 0; kj < 2; ++kj)
+      if (kj < nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = FAST ? __expf(sacc[kj][r] - m) : expf(sacc[kj][r] - m);
+          sacc[kj][r] = e;
+          sum += e;
+        }
       }
-    sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      o4[q] += __shfl_xor(o4[q], 16, 64);
-      o4[q] += __shfl_xor(o4[q], 32, 64);
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x16 oacc = {0};
+#pragma unroll
+      for (int kj = 0; kj < 2; ++kj)
+        if (kj < nt) {
+          float vv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            vv[r] = base[(size_t)min(kj * 32 + mfma32_row(r, lane), len - 1) * 768 + 512 + dt * 32 + l31];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc = mfma32(sacc[kj][r] * inv, vv[r], oacc);
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qi * 32 + mfma32_row(r, lane);
+        if (q < len) out[(size_t)(r0 + q) * 256 + h * 64 + dt * 32 + l31] = oacc[r];
+      }
     }
-    if (g == 0) *(f32x4*)(out + (size_t)(r0 + i) * 256 + h * 64 + c * 4) = o4 * (1.0f / sum);
   }
 }
 

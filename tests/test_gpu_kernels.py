@@ -166,6 +166,7 @@ def test_encode_latent(dev, ae, ae_sd):
     from style_transfer_amd.data import pack_sentences
     sents = some_sentences(40) + [[], [5]]
     sents += [sents[0] + sents[1], (sents[2] * 8)[:59], sents[3][:16], (sents[4] * 3)[:17]]   # > 16 tokens: general kernel
+    sents += [(sents[5] * 8)[:32], (sents[6] * 8)[:33], (sents[7] * 9)[:64], (sents[8] * 8)[:48]]   # tile boundaries of the MFMA form
     tok, pos, off, mx = pack_sentences(sents)
     t = lambda v: torch.from_numpy(v).to(dev)
     got = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx).cpu().numpy()
@@ -174,7 +175,7 @@ def test_encode_latent(dev, ae, ae_sd):
             assert np.abs(got[i]).max() == 0
             continue
         # padded to a longer length on purpose: padding must not change the latent
-        src = np.zeros((1, len(s) + 3), np.int64)
+        src = np.zeros((1, min(len(s) + 3, 64)), np.int64)
         src[0, :len(s)] = s
         ref = O.encode_latent(ae_sd, src)[0]
         assert relerr(got[i], ref) < 2e-4, (i, relerr(got[i], ref))

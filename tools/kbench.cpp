@@ -59,6 +59,26 @@ static double timeit(F f, int iters = 10) {
   return ms * 1e-3 / iters;
 }
 
+// Sustained MFMA rate of the chip as it runs here (power-managed clock), nothing but v_mfma_f32_32x32x16_f16 on register
+// operands: 4 independent accumulators per wave, `waves` waves per SIMD.  The roofline peak quoted from the guide assumes 2.4 GHz.
+__global__ __launch_bounds__(512) void mfma_peak_kernel(float* out, int iters) {
+  h8 a, b;
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (_Float16)(threadIdx.x * 0.001f + i);
+    b[i] = (_Float16)(blockIdx.x * 0.001f - i);
+  }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int it = 0; it < iters; ++it) {
+    c0 = mfma16h(a, b, c0);
+    c1 = mfma16h(a, b, c1);
+    c2 = mfma16h(a, b, c2);
+    c3 = mfma16h(a, b, c3);
+  }
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if (s == 1.2345f) out[threadIdx.x] = s;
+}
+
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 65536;
   g_fmt = argc > 3 ? atoi(argv[3]) : ST_GEMM_F32;  // kbench <rows> <generator splits, 0 = auto> <format>
@@ -87,6 +107,15 @@ int main(int argc, char** argv) {
   hipStream_t st = 0;
   double t;
 
+  if (want('p')) {  // sustained MFMA peak
+    for (int wg_threads : {256, 512}) {
+      const int iters = 20000;
+      t = timeit([&] { hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * 4), dim3(wg_threads), 0, st, x, iters); }, 5);
+      const double fl = 4.0 * iters * 32768.0 * (wg_threads / 64) * 256 * 4;
+      printf("mfma f16 32x32x16 only, %d waves per workgroup, 1024 workgroups: %8.1f us  %7.1f TF  (= %.2f GHz x 1024 flop/clk/SIMD x 1024 SIMDs)\n",
+             wg_threads / 64, t * 1e6, fl / t / 1e12, fl / t / 1024.0 / 1024.0 / 1e9);
+    }
+  }
   if (want('g')) {  // generator
     GemmArgs g = {};
     g.fmt = g_fmt;
