@@ -59,23 +59,36 @@ static double timeit(F f, int iters = 10) {
   return ms * 1e-3 / iters;
 }
 
-// Sustained MFMA rate of the chip as it runs here (power-managed clock), nothing but v_mfma_f32_32x32x16_f16 on register
-// operands: 4 independent accumulators per wave, `waves` waves per SIMD.  The roofline peak quoted from the guide assumes 2.4 GHz.
-__global__ __launch_bounds__(512) void mfma_peak_kernel(float* out, int iters) {
-  h8 a, b;
-  for (int i = 0; i < 8; ++i) {
-    a[i] = (_Float16)(threadIdx.x * 0.001f + i);
-    b[i] = (_Float16)(blockIdx.x * 0.001f - i);
-  }
-  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
-  for (int it = 0; it < iters; ++it) {
-    c0 = mfma16h(a, b, c0);
-    c1 = mfma16h(a, b, c1);
-    c2 = mfma16h(a, b, c2);
-    c3 = mfma16h(a, b, c3);
-  }
+// Sustained MFMA rate of the chip as it runs here (power-managed clock): nothing but f16 MFMAs on register operands,
+// RANDOM operand bits (trivial operands draw less power and hold a higher clock), `waves` waves per SIMD.
+// SHAPE 0: v_mfma_f32_32x32x16_f16, 2 accumulators;  SHAPE 1: v_mfma_f32_16x16x32_f16, 8 accumulators (same 32x32x32... flops per iteration).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__global__ __launch_bounds__(512) void mfma_peak_kernel(float* out, const float* seed, int iters) {
+  h8 a[4], b[4];
+  for (int q = 0; q < 4; ++q)
+    for (int i = 0; i < 8; ++i) {
+      a[q][i] = (_Float16)seed[(threadIdx.x * 37 + q * 8 + i) & 4095];
+      b[q][i] = (_Float16)seed[(threadIdx.x * 53 + blockIdx.x + q * 8 + i + 1000) & 4095];
+    }
   float s = 0;
-  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if (SHAPE == 0) {
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; ++it) {  // 4 x 32x32x16 = 131072 flop
+      c0 = mfma16h(a[0], b[0], c0);
+      c1 = mfma16h(a[1], b[1], c1);
+      c2 = mfma16h(a[2], b[2], c2);
+      c3 = mfma16h(a[3], b[3], c3);
+    }
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  } else {
+    f32x4v c[8] = {};
+    for (int it = 0; it < iters; ++it) {  // 8 x 16x16x32 = 131072 flop
+#pragma unroll
+      for (int q = 0; q < 8; ++q) c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q & 3], b[(q + (q >> 2)) & 3], c[q], 0, 0, 0);
+    }
+    for (int q = 0; q < 8; ++q) s += c[q][0] + c[q][1] + c[q][2] + c[q][3];
+  }
   if (s == 1.2345f) out[threadIdx.x] = s;
 }
 
@@ -107,14 +120,22 @@ int main(int argc, char** argv) {
   hipStream_t st = 0;
   double t;
 
-  if (want('p')) {  // sustained MFMA peak
-    for (int wg_threads : {256, 512}) {
-      const int iters = 20000;
-      t = timeit([&] { hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * 4), dim3(wg_threads), 0, st, x, iters); }, 5);
-      const double fl = 4.0 * iters * 32768.0 * (wg_threads / 64) * 256 * 4;
-      printf("mfma f16 32x32x16 only, %d waves per workgroup, 1024 workgroups: %8.1f us  %7.1f TF  (= %.2f GHz x 1024 flop/clk/SIMD x 1024 SIMDs)\n",
-             wg_threads / 64, t * 1e6, fl / t / 1e12, fl / t / 1024.0 / 1024.0 / 1e9);
-    }
+  if (want('p')) {  // sustained MFMA peak, both f16 shapes, random operands
+    float* seed = dev_rand(4096, 2.0f, 77);
+    for (int rep = 0; rep < 2; ++rep)
+      for (int shape = 0; shape < 2; ++shape)
+        for (int wg_threads : {256, 512}) {
+          const int iters = 20000;
+          t = timeit([&] {
+            if (shape == 0)
+              hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(256 * 4), dim3(wg_threads), 0, st, x, seed, iters);
+            else
+              hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(256 * 4), dim3(wg_threads), 0, st, x, seed, iters);
+          }, 5);
+          const double fl = 131072.0 * iters * (wg_threads / 64) * 256 * 4;
+          printf("bare %s f16 MFMA loop, random operands, %d waves per SIMD: %8.1f us  %7.1f TF  (= %.2f GHz x 1024 flop/clk/SIMD x 1024 SIMDs)\n",
+                 shape ? "16x16x32" : "32x32x16", wg_threads / 256, t * 1e6, fl / t / 1e12, fl / t / 1024.0 / 1024.0 / 1e9);
+        }
   }
   if (want('g')) {  // generator
     GemmArgs g = {};
