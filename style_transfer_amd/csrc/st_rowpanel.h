@@ -1736,6 +1736,285 @@ static int launch_layer_tail32(const OFArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same half-layer on v_mfma_f32_16x16x32_f16 tiles.  The chip lowers its clock under matrix load and the clock it
+// holds depends on the MFMA shape: a bare loop of the 32x32x16 form on random operands sustains 1.61 PFLOP/s here, the
+// 16x16x32 form 1.82 (profiles/r02_mfma_sustained_rate.txt).  Same LDS panels, same packed weights (read through
+// different lane addresses), same persistent panel loop; what changes:
+//  * EVERY product is computed in the orientation the 64-row kernel uses for FFN1 only: the W fragment is the A
+//    operand (16 output features x 32 k), the panel fragment the B operand (32 k x 16 panel rows).  Lane (r16 = l & 15,
+//    g = l >> 4) then holds features 4g .. 4g+3 of panel row r16 in one accumulator: the residual loads, the x1 -> LDS
+//    writes, the hidden-chunk writes and the final stores are 16-byte accesses (8 per lane instead of 32 dwords).
+//  * A pass is 8 double k-steps (K = 32) of two half-steps (row tiles {0,1}, {2,3}); a half-step issues 12 MFMAs (192
+//    cycles, as one k-step of the 32x32x16 form) from 4 panel fragments and the double step's 4 W fragments.
+// W fragment of k-steps (2d, 2d+1), feature tile ft, lane (r16, g): k = 32d + 8g .. +7 lives in the packed image at
+// k-step 2d + (g >> 1), lane 16 ft + r16 + 32 (g & 1): four 256-byte runs per wave load.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma16x32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* P1 = smem;
+  float* P2 = smem + 64 * ST_LDA;
+  int* sIdx = (int*)(smem + 2 * 64 * ST_LDA);
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int mstride = gridDim.x * 64;
+  int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int r16 = lane & 15, g = lane >> 4;
+  int fcol = wave * 32 + 4 * g;  // this lane's first output feature of feature tile 0 (tile 1: + 16)
+  const int nchunk = a.d_ff >> 8;
+  TSTAMP(31);
+
+  f32x4 rw[2][4];  // W ring, two double steps deep: [slot][2 * ft + lo]
+  auto wfetch = [&](const f32x4* Wl, int d, f32x4 (&dst)[4]) {
+    dst[0] = Wl[d * 256];
+    dst[1] = Wl[d * 256 + 64];
+    dst[2] = Wl[d * 256 + 16];
+    dst[3] = Wl[d * 256 + 80];
+  };
+
+  int bad = 0;    // an operand left the f16 range (or is NaN): reported once at the end
+  f32x4 attr[8];  // this thread's share of an attention panel on its way from HBM to P1
+  auto att_load = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + i * 512;
+      attr[i] = *(const f32x4*)(a.att + (size_t)min(mb + (f >> 6), n - 1) * 256 + (f & 63) * 4);
+    }
+  };
+  auto att_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + i * 512;
+      panel_store4_nb(P1 + (f >> 6) * ST_LDA, f & 63, attr[i], bad);
+    }
+  };
+  f32x4 ax[2][4], px[2][4], pc[2][4];  // [feature tile][row tile]
+  auto idx_stage = [&](int mb) {
+    if (a.cconst && tid < 64) sIdx[tid] = a.idx[min(mb + tid, n - 1)];
+  };
+  auto resid_load = [&](int mb) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const float* xr = a.x + (size_t)min(mb + 16 * rt + r16, n - 1) * 256 + fcol;
+      px[0][rt] = *(const f32x4*)xr;
+      px[1][rt] = *(const f32x4*)(xr + 16);
+    }
+    if (a.cconst) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const float* cr = a.cconst + (size_t)sIdx[16 * rt + r16] * 256 + fcol;
+        pc[0][rt] = *(const f32x4*)cr;
+        pc[1][rt] = *(const f32x4*)(cr + 16);
+      }
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) pc[0][rt] = pc[1][rt] = f32x4{0, 0, 0, 0};
+    }
+  };
+  att_load(m0);
+  idx_stage(m0);
+  const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+  const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+  f32x4 b1n[2];  // FFN1 bias of this lane's 8 hidden units in the coming chunk
+  auto b1_fetch = [&](int c) {
+    b1n[0] = *(const f32x4*)(a.b1 + (c * 8 + wave) * 32 + 4 * g);
+    b1n[1] = *(const f32x4*)(a.b1 + (c * 8 + wave) * 32 + 16 + 4 * g);
+  };
+  att_store();
+  __syncthreads();  // sIdx of the first panel
+  resid_load(m0);
+  bool first = true;
+  for (;;) {
+  // (lane coordinates from an opaque copy of the thread index: see rp_layer_tail_kernel)
+  TSTAMP(35);
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
+  r16 = lane & 15;
+  g = lane >> 4;
+  fcol = wave * 32 + 4 * g;
+  const int wlane = (g >> 1) * 128 + 32 * (g & 1) + r16;  // this lane's place inside a double step of a packed block
+  const f32x4* Wo = (const f32x4*)a.wo + (size_t)wave * 16 * 128 + wlane;
+  auto W1p = [&](int c) { return (const f32x4*)a.w1 + (size_t)(c * 8 + wave) * 16 * 128 + wlane; };                  // hidden block 8c + wave
+  auto W2p = [&](int c) { return (const f32x4*)a.w2 + ((size_t)wave * (a.d_ff >> 4) + c * 16) * 128 + wlane; };  // k-steps 16c .. 16c+15 of output block `wave`
+  if (first) {
+    wfetch(Wo, 0, rw[0]);
+    wfetch(Wo, 1, rw[1]);
+  }
+  first = false;
+  {
+    const f32x4 bo0 = *(const f32x4*)(a.bo + fcol), bo1 = *(const f32x4*)(a.bo + fcol + 16);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      ax[0][rt] = bo0;
+      ax[1][rt] = bo1;
+    }
+  }
+  TSTAMP(0);
+  __syncthreads();
+  TSTAMP(1);
+  const float* A1 = P1 + r16 * ST_LDA + 4 * g;  // panel fragment base (row tile 0, double step 0, hi)
+  const float* A2 = P2 + r16 * ST_LDA + 4 * g;
+  // One pass over K = 256: acc[ft][rt] += W[features of tile ft] . panel[rows of tile rt]^T.  With EPI the accumulators
+  // o of the previous hidden chunk are converted (ReLU, f16 split) and written to P2 in the MFMAs' shadow.
+  _Float16* H2 = (_Float16*)P2;
+  auto epi_unit = [&](const f32x4& acc, int ft, int rt) {
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = fmaxf(acc[q], 0.0f);
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    bad |= !(mx <= 65504.0f);
+    h4 hi, lo;
+    split_f16(v, hi, lo);
+    _Float16* dst = H2 + (size_t)(16 * rt + r16) * (2 * ST_LDA) + fcol + 16 * ft;
+    *(h4*)dst = hi;
+    *(h4*)(dst + 256) = lo;
+  };
+  auto pass = [&](const float* Pb, const f32x4* Wc, const f32x4* Wn, f32x4 (&acc)[2][4], const bool epi, const f32x4 (&o)[2][4]) {
+    f32x4 pn[4];  // panel fragments of the next half-step: row tile 2hf (hi, lo), row tile 2hf + 1 (hi, lo)
+    pn[0] = *(const f32x4*)(Pb);
+    pn[1] = *(const f32x4*)(Pb + 128);
+    pn[2] = *(const f32x4*)(Pb + 16 * ST_LDA);
+    pn[3] = *(const f32x4*)(Pb + 16 * ST_LDA + 128);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int slot = d & 1;
+      const h8 wh0 = as_h8(rw[slot][0]), wl0 = as_h8(rw[slot][1]), wh1 = as_h8(rw[slot][2]), wl1 = as_h8(rw[slot][3]);
+      if (d + 2 < 8)
+        wfetch(Wc, d + 2, rw[slot]);
+      else
+        wfetch(Wn, d + 2 - 8, rw[slot]);  // the ring never drains: the next pass's first double steps
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+        if (!(d == 7 && hf == 1)) {
+          const int nd = hf ? d + 1 : d, nrt = hf ? 0 : 2;
+          const float* q = Pb + nrt * 16 * ST_LDA + 16 * nd;
+          pn[0] = *(const f32x4*)(q);
+          pn[1] = *(const f32x4*)(q + 128);
+          pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+          pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+        }
+        const int rt = 2 * hf;
+        acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
+        if (epi && hf == 1) epi_unit(o[d & 1][d >> 1], d & 1, d >> 1);  // 8 conversion units over the 8 double steps
+        __builtin_amdgcn_sched_barrier(0);  // keep the half-step structure (see rp_layer_tail_kernel)
+      }
+    }
+  };
+  pass(A1, Wo, W1p(0), ax, false, ax);
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) ax[ft][rt] += px[ft][rt] + pc[ft][rt];
+  TSTAMP(2);
+  b1_fetch(0);
+  if (m0 + mstride < n) idx_stage(m0 + mstride);  // read by resid_load in the last chunk, many barriers from here
+  __syncthreads();  // every wave is done reading the attention panel
+  TSTAMP(3);
+  // ---- x1 -> P1 (f32), LayerNorm + split in place ----
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) *(f32x4*)(P1 + (16 * rt + r16) * ST_LDA + fcol + 16 * ft) = ax[ft][rt];
+  TSTAMP(32);
+  __syncthreads();
+  TSTAMP(33);
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    float* row = P1 + (wave * 8 + rr) * ST_LDA;
+    panel_store4_nb(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
+  }
+  {
+    const f32x4 b20 = *(const f32x4*)(a.b2 + fcol), b21 = *(const f32x4*)(a.b2 + fcol + 16);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      ax[0][rt] += b20;
+      ax[1][rt] += b21;
+    }
+  }
+  TSTAMP(34);
+  __syncthreads();
+  TSTAMP(4);
+  auto ah_init = [&](f32x4 (&h)[2][4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      h[0][rt] = b1n[0];
+      h[1][rt] = b1n[1];
+    }
+  };
+  // ---- FFN1 of hidden chunk 0 (hidden block 8c + wave) ----
+  f32x4 ah[2][4];
+  ah_init(ah);
+  if (nchunk > 1) b1_fetch(1);  // consumed one chunk later
+  TSTAMP(5);
+  pass(A1, W1p(0), nchunk > 1 ? W1p(1) : W2p(0), ah, false, ah);
+  TSTAMP(6);
+  for (int c = 0; c + 1 < nchunk; ++c) {
+    f32x4 an[2][4];
+    ah_init(an);
+    if (c + 2 < nchunk) b1_fetch(c + 2);
+    if (c > 0) __syncthreads();  // every wave is done reading the previous hidden chunk
+    // ---- hidden chunk c -> P2, overlapped with FFN1 of chunk c + 1 ----
+    pass(A1, W1p(c + 1), W2p(c), an, true, ah);
+    TSTAMP(7 + c * 5);
+    __syncthreads();  // hidden chunk complete
+    TSTAMP(8 + c * 5);
+    // ---- FFN2 partial: x += h_c . W2[:, chunk]^T ----
+    pass(A2, W2p(c), c + 2 < nchunk ? W1p(c + 2) : W2p(c + 1), ax, false, ax);
+    TSTAMP(9 + c * 5);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) ah[ft][rt] = an[ft][rt];
+  }
+  {  // last chunk (peeled, with the next panel's loads: see rp_layer_tail_kernel)
+    const int c = nchunk - 1;
+    att_load(m0 + mstride);
+    resid_load(m0 + mstride);
+    if (c > 0) __syncthreads();
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) epi_unit(ah[ft][rt], ft, rt);
+    TSTAMP(7 + c * 5);
+    __syncthreads();  // hidden chunk complete
+    TSTAMP(8 + c * 5);
+    pass(A2, W2p(c), Wo, ax, false, ax);  // (a workgroup's last panel requests Wo once more and drops it)
+    TSTAMP(9 + c * 5);
+  }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int row = m0 + 16 * rt + r16;
+    if (row < n) {
+      __builtin_nontemporal_store(ax[0][rt], (f32x4*)(a.x + (size_t)row * 256 + fcol));
+      __builtin_nontemporal_store(ax[1][rt], (f32x4*)(a.x + (size_t)row * 256 + fcol + 16));
+    }
+  }
+  TSTAMP(30);
+  m0 += mstride;
+  if (m0 >= n) break;
+  att_store();
+  TSTAMP(36);
+  }  // panels of this workgroup
+  if (bad && a.range_flag) *a.range_flag = 1;
+}
+
 static int rp_tail_persistent = 1;  // tools/kbench.cpp clears it for the one-panel-per-workgroup A/B
 static inline int st_cu_count() {
   static int cus[16] = {0};
@@ -1761,11 +2040,28 @@ static int launch_layer_tail64(const OFArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
+static int rp_tail_shape16 = 1;  // 1: the 16x16x32 form; tools/kbench.cpp flips it for the A/B
+static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
+  ST_ENSURE_LDS((rp_layer_tail16_kernel<0>), RP_TAIL_LDS);
+  if (n_bound <= 0) return ST_OK;
+  if (a.fmt != ST_GEMM_F16X3 || a.d_ff % 256 != 0 || !a.w2 || !a.b2) {
+    st_set_error("rp_layer_tail16: needs the f16x3 format, d_ff %% 256 == 0 and w2/b2 (fmt=%d d_ff=%d)", a.fmt, a.d_ff);
+    return ST_EINVAL;
+  }
+  int grid = (n_bound + 63) / 64;
+  if (rp_tail_persistent) grid = std::min(grid, st_cu_count());
+  hipLaunchKernelGGL(rp_layer_tail16_kernel<0>, dim3(grid), dim3(512), RP_TAIL_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
 // The library uses the 64-row kernel: the 32-row / two-workgroups-per-CU form measured 8 % SLOWER (kbench A/B at 131072
 // and 229376 rows, bit-identical outputs; profiles/r02_kbench_tail_ab.txt): it hides the panel load, LayerNorm, store and
 // turnaround phases as intended, but every W fragment feeds three MFMAs instead of six and the doubled L2 -> CU weight
 // stream costs more than the overlap gains.  launch_layer_tail32 stays reachable from tools/kbench.cpp only.
-static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) { return launch_layer_tail64(a, n_bound, st); }
+static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) {
+  return rp_tail_shape16 ? launch_layer_tail16(a, n_bound, st) : launch_layer_tail64(a, n_bound, st);
+}
 
 // packed-weight helpers -------------------------------------------------------------------------
 static inline size_t rp_packed_floats(int N, int K) { return (size_t)((N + 31) / 32) * 32 * K; }

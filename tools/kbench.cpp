@@ -235,6 +235,35 @@ int main(int argc, char** argv) {
       printf("  outputs: %zu of %zu elements differ bitwise\n", diff, x0.size());
       CK(hipFree(xs));
     }
+    {
+      // A/B: 16x16x32 tiles vs 32x32x16 tiles (both persistent); outputs compared by value (the MFMA-internal summation order differs)
+      double t16 = 0, t32x = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        t16 += timeit([&] { launch_layer_tail16(a, n, st); }, 5);
+        t32x += timeit([&] { launch_layer_tail64(a, n, st); }, 5);
+      }
+      printf("layer tail A/B n=%d: 16x16x32 tiles %8.1f us   32x32x16 tiles %8.1f us  (%.3f)\n", n, t16 / 3 * 1e6, t32x / 3 * 1e6, t16 / t32x);
+      std::vector<float> x0((size_t)n * 256), ya(x0.size()), yb(x0.size());
+      float* xs = dev_rand((size_t)n * 256, 1.0f, 1);
+      CK(hipMemcpy(x0.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      OFArgs b = a;
+      b.x = xs;
+      launch_layer_tail16(b, n, st);
+      CK(hipMemcpy(ya.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(xs, x0.data(), x0.size() * 4, hipMemcpyHostToDevice));
+      launch_layer_tail64(b, n, st);
+      CK(hipMemcpy(yb.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
+      double mx = 0, ref = 0;
+      size_t diff = 0;
+      for (size_t i = 0; i < x0.size(); ++i) {
+        mx = fmax(mx, fabs((double)ya[i] - (double)yb[i]));
+        ref = fmax(ref, fabs((double)yb[i]));
+        diff += memcmp(&ya[i], &yb[i], 4) != 0;
+      }
+      printf("  outputs: max |diff| %.3g against max |y| %.3g, %zu of %zu elements differ bitwise; samples %g %g | %g %g\n", mx, ref, diff, x0.size(),
+             ya[12345], yb[12345], ya[x0.size() - 7], yb[x0.size() - 7]);
+      CK(hipFree(xs));
+    }
     if (getenv("KBENCH_TAIL32")) {
       // A/B: the 32-row / 4-wave form (two workgroups per CU), interleaved rounds, and a bitwise comparison of the outputs
       double t64 = 0, t32 = 0;
@@ -264,7 +293,8 @@ int main(int argc, char** argv) {
     }
 #ifdef ST_TAIL_STAMPS
     rp_tail_persistent = getenv("KBENCH_ONE_PANEL") ? 0 : 1;
-    launch_layer_tail64(a, n, st);
+    rp_tail_shape16 = getenv("KBENCH_SHAPE32") ? 0 : 1;
+    launch_layer_tail(a, n, st);
     CK(hipDeviceSynchronize());
     rp_tail_persistent = 1;
     unsigned long long hs[64];
