@@ -29,6 +29,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 # v_mfma_f32_32x32x16_f16 = 32768 flop / 32 clk
 F32_MFMA_PEAK_TFLOPS = 157.3
 F16_MFMA_PEAK_TFLOPS = 2516.6
+SUSTAINED_F16_16x16x32_TFLOPS = 1820.0   # measured: profiles/r02_mfma_sustained_rate.txt (32x32x16: 1610)
 
 
 def cpu_baseline(seconds_budget=20.0, shape="yelp"):
@@ -492,8 +493,9 @@ def main(argv=None):
             # achieved = ALGORITHMIC flops of the timed kernel / its HIP-event time.  f16x3 issues 3 MFMA flops per
             # algorithmic flop, so frac <= 1/3 there by construction; mfma_issue_frac counts the issued ones.
             "roofline": {"bound": "mfma",
-                         "kernel": ("rp_layer_tail_kernel (O-projection + residual + LayerNorm + FFN1 + FFN2 on one 64-row panel; "
-                                    "2*rows*256*(256+2*d_ff) flop per launch; largest share of GPU time in this format)") if split
+                         "kernel": ("rp_layer_tail16_kernel (O-projection + residual + LayerNorm + FFN1 + FFN2 on 64-row panels, persistent "
+                                    "over panels, v_mfma_f32_16x16x32_f16; 2*rows*256*(256+2*d_ff) flop per launch; largest share of GPU "
+                                    "time in this format)") if split
                                    else "rp_gemm_kernel<EPI_ARGMAX,4,false> (generator GEMM + fused argmax; 2*rows*256*V flop per launch)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
@@ -502,6 +504,9 @@ def main(argv=None):
                          "mfma_flops_per_algorithmic_flop": 3 if split else 1,
                          "mfma_issue_frac": achieved * (3 if split else 1) / peak,
                          "achieved_over_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
+                         # a bare loop of this MFMA shape on random operands sustains 1.82 PFLOP/s on this chip (power-managed
+                         # clock; tools/kbench.cpp `p`, profiles/r02_mfma_sustained_rate.txt) - the guide's 2516.6 assumes 2.4 GHz
+                         "mfma_issue_frac_of_sustained_rate": (achieved * 3 / SUSTAINED_F16_16x16x32_TFLOPS) if split else None,
                          "launches": int(gen_n.value), "avg_launch_us": gen_ms.value * 1e3 / max(1, gen_n.value),
                          "kernel_time_share": gen_ms.value * 1e-3 / dt},
         }
