@@ -412,6 +412,13 @@ def main(argv=None):
         rl.ws.buf = rl2.ws.buf = None
         del rl, rl2
         fresh()
+        # (3b) BASELINE config 2's regime: batch 256 (latency-bound: every decode step is ~25 launches on a few hundred rows)
+        tiny = [runner.prepare(s.span(0, 256)) for s in sets[:2]]
+        r256 = AttackRunner(ae, scorer, cfg, dev)
+        side["batch_256_sentences_per_s"] = timed(r256, tiny, 4)
+        r256.ws.buf = None
+        del r256
+        fresh()
         # (4) end to end: token arrays on the HOST -> pack -> H2D -> attack -> compact records D2H -> log text -> file,
         # software-pipelined over the batches (style_transfer_amd/pipeline.py), the product CLI's path
         import tempfile
