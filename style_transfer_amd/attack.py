@@ -175,9 +175,11 @@ class AttackRunner:
         self.canon = None
 
     def set_vocab(self, id_to_word):
-        from .data import canonical_ids
+        from .data import canonical_ids, last_ids
         c = canonical_ids(id_to_word)
         self.canon = None if c is None else torch.from_numpy(c).to(self.device)
+        m = last_ids(id_to_word)      # --retext: a word spelled by several ids re-encodes as the last of them
+        self.retext_map = None if m is None else torch.from_numpy(m).to(self.device)
 
     # -- pieces -----------------------------------------------------------------------------------
     ENC_CHUNK = 32768  # sentences per encoder launch sequence (bounds the [rows, d_ff] workspace)
@@ -208,8 +210,8 @@ class AttackRunner:
 
     def reencode(self, ids):
         """--retext (siamese_contrastive.py:842-855): decoded ids [n,T] -> text -> ids -> latent.  The text
-        is the id prefix before the first EOS/PAD (data.py:43-52) and word <-> id is one-to-one, so the
-        re-encoded sentence is that prefix; packing happens on the device (torch indexing = plumbing)."""
+        is the id prefix before the first EOS/PAD (data.py:43-52); ids go through `retext_map` (identity for the
+        shipped vocabularies, which have no duplicate words); packing happens on the device (torch indexing = plumbing)."""
         c = self.cfg
         n, T = ids.shape
         term = (ids == c.id_eos) | (ids == c.id_pad)
@@ -217,6 +219,8 @@ class AttackRunner:
         ar = torch.arange(T, device=ids.device)
         mask = ar[None, :] < lens[:, None]
         tokens = ids[mask].to(torch.int32).contiguous()
+        if getattr(self, "retext_map", None) is not None:
+            tokens = self.retext_map[tokens.long().clamp_(0, self.retext_map.numel() - 1)].contiguous()
         tok_pos = ar.to(torch.int32)[None, :].expand(n, T)[mask].contiguous()
         off = torch.zeros(n + 1, dtype=torch.int32, device=ids.device)
         off[1:] = torch.cumsum(lens, 0).to(torch.int32)

@@ -181,6 +181,16 @@ __global__ __launch_bounds__(256) void enc_latent_kernel(const float* __restrict
   *(f32x4*)(latent + (size_t)s * 256 + lane * 4) = acc;
 }
 
+// A sentence longer than the caller's max_sent_len (or than 64) would be skipped by both attention kernels and leave
+// stale workspace rows behind: found here and reported as ST_EINVAL (second flag word; the first = f16 range).
+__global__ __launch_bounds__(256) void enc_check_len_kernel(const int32_t* __restrict__ off, int n_sent, int max_len, int n_rows,
+                                                            int* __restrict__ flag) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_sent) return;
+  const int len = off[s + 1] - off[s];
+  if (len < 0 || len > max_len || off[s] < 0 || off[s + 1] > n_rows) flag[1] = 1;
+}
+
 static inline size_t enc_align(size_t v) { return (v + 255) / 256 * 256; }
 
 extern "C" size_t st_encode_workspace_bytes(const StEncoderWeights* w, int n_rows, int n_sent) {
@@ -219,8 +229,9 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
   float* qkv = (float*)base; base += enc_align((size_t)n_rows * 768 * 4);
   float* h = (float*)base; base += enc_align((size_t)n_rows * w->d_ff * 4);
   int* range_flag = (int*)base;
-  ST_HIP(hipMemsetAsync(range_flag, 0, sizeof(int), st));
+  ST_HIP(hipMemsetAsync(range_flag, 0, 2 * sizeof(int), st));
   const int R = n_rows;
+  hipLaunchKernelGGL(enc_check_len_kernel, dim3((n_sent + 255) / 256), dim3(256), 0, st, sent_off, n_sent, max_sent_len, n_rows, range_flag);
   hipLaunchKernelGGL(enc_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->emb, w->pe, tokens, tok_pos, R, w->vocab, x);
   ST_LAUNCH_CHECK();
   for (int l = 0; l < w->n_layers; ++l) {
@@ -278,11 +289,16 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
   }
   hipLaunchKernelGGL(enc_latent_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, x, sent_off, n_sent, w->lnf_a, w->lnf_b, latent);
   ST_LAUNCH_CHECK();
-  if (w->gemm_format == ST_GEMM_F16X3) {  // the only synchronisation of this entry point, and only in this format
-    int flag = 0;
-    ST_HIP(hipMemcpyAsync(&flag, range_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  {  // the only synchronisation of this entry point: the flag word
+    int flag[2] = {0, 0};
+    ST_HIP(hipMemcpyAsync(flag, range_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     ST_HIP(hipStreamSynchronize(st));
-    if (flag) {
+    if (flag[1]) {
+      st_set_error("st_encode_latent: sent_off holds a sentence longer than max_sent_len=%d (or offsets outside [0, n_rows]); "
+                   "the latents are invalid", max_sent_len);
+      return ST_EINVAL;
+    }
+    if (flag[0]) {
       st_set_error("st_encode_latent: an activation left the f16 range (|x| >= 65504 or NaN) in the f16x3 format; "
                    "the latents are invalid - pack the weights with ST_GEMM_F32");
       return ST_ERANGE;

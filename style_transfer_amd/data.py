@@ -48,6 +48,14 @@ def canonical_ids(id_to_word):
     return None if ident else canon
 
 
+def last_ids(id_to_word):
+    """id -> LAST id spelling the same word: what text -> `word_to_id[w]` gives when the dictionary was filled in id
+    order (main.py:194-197; --retext re-encodes through it, siamese_contrastive.py:746-751).  None if identity."""
+    last = {w: i for i, w in enumerate(id_to_word)}
+    m = np.fromiter((last[w] for w in id_to_word), np.int32, len(id_to_word))
+    return None if (m == np.arange(len(id_to_word))).all() else m
+
+
 def id2text_sentence(sen_id, id_to_word):
     """data.py:43-52."""
     sen_text = []

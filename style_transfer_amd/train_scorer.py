@@ -127,7 +127,10 @@ class ScorerTrainer:
             if tuple(keep_masks.shape) != (1 + Kp + Kn, 2, B, 512):
                 raise ValueError("keep_masks must be [1+Kp+Kn, 2, B, 512]")
         if seed is None:
-            seed = (cfg.seed * 0x9E3779B1 + self.step_no) & 0xFFFFFFFFFFFFFFFF
+            # the rank is part of the seed: the kernel hashes (seed, LOCAL element), and the reference draws independent
+            # masks for every row of the global batch
+            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+            seed = (cfg.seed * 0x9E3779B1 + self.step_no + rank * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         check(lib().st_scorer_train_step(_p(self.params), _p(self.bn), _p(x), B, Kp, Kn, cfg.tau, flags, cfg.drop_p,
                                          _p(keep_masks), C.c_uint64(seed), _p(self.grads), _p(self.loss), _p(self._choice),
                                          _p(self._ws), self._ws.numel(), _stream()), "st_scorer_train_step")

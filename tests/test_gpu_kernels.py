@@ -181,6 +181,19 @@ def test_encode_latent(dev, ae, ae_sd):
         assert relerr(got[i], ref) < 2e-4, (i, relerr(got[i], ref))
 
 
+def test_encode_latent_rejects_a_sentence_longer_than_declared(dev, ae):
+    """st_encode_latent must not return ST_OK with stale attention rows when sent_off holds a sentence longer than the
+    caller's max_sent_len (the attention kernels skip it): ST_EINVAL."""
+    from style_transfer_amd import ops
+    from style_transfer_amd.data import pack_sentences
+    sents = some_sentences(6) + [(some_sentences(1)[0] * 9)[:40]]
+    tok, pos, off, mx = pack_sentences(sents)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx)      # the true maximum: fine
+    with pytest.raises(Exception, match="max_sent_len"):
+        ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), 16)
+
+
 @pytest.mark.parametrize("early", [True, False])
 def test_greedy_decode(dev, ae, ae_sd, early):
     from style_transfer_amd import ops
