@@ -65,6 +65,10 @@ __device__ __forceinline__ void panel_store4_nb(float* row, int c4, f32x4 v, int
   *(h4*)(ph + 256 + c4 * 4) = lo;
 }
 
+// D(16 x 16) += A(16 x 32) . B(32 x 16) on f16: lane l holds A[row l & 15][k = 8 (l >> 4) .. +7], B[k = same][col l & 15];
+// D: col = l & 15, rows 4 (l >> 4) .. +3 in the four registers
+__device__ __forceinline__ f32x4 mfma16x32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 template <int EPI, int NW = 4, bool H = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -725,11 +729,178 @@ __global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
   }
   if (bad && a.range_flag) *a.range_flag = 1;
 }
+// ------------------------------------------------------------------------------------------------
+// rp_lin_kernel on v_mfma_f32_16x16x32_f16 tiles with W as the A operand (see rp_layer_tail16_kernel for the lane
+// addressing of the unchanged packed image and LDS panel): the shape the power-managed chip clocks higher on, and an
+// epilogue of 8 16-byte stores per lane and block (4 consecutive features of one row) instead of 32 dwords.
+// Needs N % 32 == 0 and 16-byte aligned output rows (ldo % 4, kv_stride % 4).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void rp_lin16_kernel(GemmArgs a) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_QKV, "rp_lin16_kernel: BIAS or QKV");
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;  // [64][ST_LDA]
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  int bad = 0;
+  if (a.ln_a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 6, c4 = f & 63;
+      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+    }
+    __syncthreads();
+    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      float* row = As + (wave * 16 + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
+      panel_store4_nb(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 6, c4 = f & 63;
+      panel_store4_nb(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4), bad);
+    }
+  }
+  int* slot = (int*)(smem + 64 * ST_LDA);  // QKV: the K/V cache slot (job) of each panel row
+  if (EPI == EPI_QKV && tid < 64) slot[tid] = a.idx[min(m0 + tid, n - 1)];
+  __syncthreads();
+
+  const int nblk = (a.N + 31) >> 5;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;  // column split blockIdx.y covers blocks [b0, b1)
+  const int b0 = blockIdx.y * per;
+  const int b1 = min(nblk, b0 + per);
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) / 4 : 0;  // this wave's blocks: b0 + wave, b0 + wave + 4, ...
+  const f32x4* Wl = (const f32x4*)a.W + (g >> 1) * 128 + 32 * (g & 1) + r16;
+  const float* Ab = As + r16 * ST_LDA + 4 * g;
+  auto wbase = [&](int i) -> const f32x4* { return Wl + (size_t)(b0 + wave + 4 * min(i, cnt - 1)) * 16 * 128; };
+  auto wfetch = [&](const f32x4* Wb, int d, f32x4 (&dst)[4]) {
+    dst[0] = Wb[d * 256];
+    dst[1] = Wb[d * 256 + 64];
+    dst[2] = Wb[d * 256 + 16];
+    dst[3] = Wb[d * 256 + 80];
+  };
+  auto put = [&](const f32x4& v, int i, int ft, int rt) {
+    const int blk = b0 + wave + 4 * i;  // wave-uniform: a 32-column block lies entirely in q, k or v
+    const int col = (blk << 5) + 16 * ft + 4 * g;
+    const int rl = 16 * rt + r16;
+    if (m0 + rl >= n) return;
+    if (EPI == EPI_BIAS) {
+      __builtin_nontemporal_store(v, (f32x4*)&a.out[(size_t)(m0 + rl) * a.ldo + col]);
+    } else if (blk < 8) {
+      __builtin_nontemporal_store(v, (f32x4*)&a.q[(size_t)(m0 + rl) * 256 + col]);
+    } else {
+      float* base = (blk < 16) ? a.kbase : a.vbase;
+      __builtin_nontemporal_store(v, (f32x4*)&base[(long)slot[rl] * a.kv_stride + (col & 255)]);
+    }
+  };
+  f32x4 rw[2][4];
+  if (cnt > 0) {
+    wfetch(wbase(0), 0, rw[0]);
+    wfetch(wbase(0), 1, rw[1]);
+  }
+  f32x4 pn[4];
+  pn[0] = *(const f32x4*)(Ab);
+  pn[1] = *(const f32x4*)(Ab + 128);
+  pn[2] = *(const f32x4*)(Ab + 16 * ST_LDA);
+  pn[3] = *(const f32x4*)(Ab + 16 * ST_LDA + 128);
+  // one block: 8 double k-steps into acc; meanwhile the previous block's accumulators (o; block number io) are stored,
+  // one 16-byte store per double step
+  auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_put) {
+    const f32x4* Wb = wbase(i);
+    const f32x4* Wn = wbase(i + 1);
+    {
+      const int col = ((b0 + wave + 4 * i) << 5) + 4 * g;
+      const f32x4 z = {0, 0, 0, 0};
+      const f32x4 bv0 = a.bias ? *(const f32x4*)(a.bias + col) : z, bv1 = a.bias ? *(const f32x4*)(a.bias + col + 16) : z;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[0][rt] = bv0;
+        acc[1][rt] = bv1;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int sl = d & 1;
+      const h8 wh0 = as_h8(rw[sl][0]), wl0 = as_h8(rw[sl][1]), wh1 = as_h8(rw[sl][2]), wl1 = as_h8(rw[sl][3]);
+      if (d + 2 < 8)
+        wfetch(Wb, d + 2, rw[sl]);
+      else
+        wfetch(Wn, d + 2 - 8, rw[sl]);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+        {
+          const int nd = hf ? ((d + 1) & 7) : d, nrt = hf ? 0 : 2;
+          const float* q = Ab + nrt * 16 * ST_LDA + 16 * nd;
+          pn[0] = *(const f32x4*)(q);
+          pn[1] = *(const f32x4*)(q + 128);
+          pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+          pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+        }
+        const int rt = 2 * hf;
+        acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
+        if (do_put && hf == 1) put(o[d & 1][d >> 1], io, d & 1, d >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  f32x4 A[2][4], B[2][4];
+  if (cnt > 0) {
+    block(A, 0, A, 0, false);
+    int i = 1;
+    for (; i + 1 < cnt; i += 2) {
+      block(B, i, A, i - 1, true);
+      block(A, i + 1, B, i, true);
+    }
+    if (i < cnt) {
+      block(B, i, A, i - 1, true);
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) put(B[ft][rt], i, ft, rt);
+    } else {
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) put(A[ft][rt], cnt - 1, ft, rt);
+    }
+  }
+  if (bad && a.range_flag) *a.range_flag = 1;
+}
+static int rp_lin_shape16 = 1;  // tools/kbench.cpp flips it for the A/B
 template <int EPI>
 static int launch_rp_lin_pipelined(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   ST_ENSURE_LDS((rp_lin_kernel<EPI>), RP_LDS);
+  ST_ENSURE_LDS((rp_lin16_kernel<EPI>), RP_LDS);
   if (n_bound <= 0) return ST_OK;
-  hipLaunchKernelGGL((rp_lin_kernel<EPI>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
+  const bool aligned = a.N % 32 == 0 && (EPI == EPI_BIAS ? (a.ldo % 4 == 0 && ((size_t)a.out & 15) == 0)
+                                                        : (a.kv_stride % 4 == 0 && ((size_t)a.q & 15) == 0 && ((size_t)a.kbase & 15) == 0 &&
+                                                           ((size_t)a.vbase & 15) == 0)) &&
+                       (!a.bias || ((size_t)a.bias & 15) == 0);
+  if (rp_lin_shape16 && aligned)
+    hipLaunchKernelGGL((rp_lin16_kernel<EPI>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
+  else
+    hipLaunchKernelGGL((rp_lin_kernel<EPI>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
@@ -1750,8 +1921,6 @@ static int launch_layer_tail32(const OFArgs& a, int n_bound, hipStream_t st) {
 // W fragment of k-steps (2d, 2d+1), feature tile ft, lane (r16, g): k = 32d + 8g .. +7 lives in the packed image at
 // k-step 2d + (g >> 1), lane 16 ft + r16 + 32 (g & 1): four 256-byte runs per wave load.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 mfma16x32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-
 template <int UNUSED = 0>
 __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   extern __shared__ __align__(16) float smem[];

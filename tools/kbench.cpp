@@ -173,8 +173,29 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_rp<EPI_BIAS, 8>(g, n, sp, st); });
     printf("qkv NW=8   n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
     if (g_fmt == ST_GEMM_F16X3) {
-      t = timeit([&] { launch_rp_lin_pipelined<EPI_BIAS>(g, n, sp, st); });
-      printf("qkv pipelined stores n=%d: %8.1f us %6.1f TF\n", n, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
+      double t16 = 0, t32x = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        rp_lin_shape16 = 1;
+        t16 += timeit([&] { launch_rp_lin_pipelined<EPI_BIAS>(g, n, sp, st); }, 5);
+        rp_lin_shape16 = 0;
+        t32x += timeit([&] { launch_rp_lin_pipelined<EPI_BIAS>(g, n, sp, st); }, 5);
+      }
+      printf("qkv pipelined stores n=%d: 16x16x32 %8.1f us %6.1f TF   32x32x16 %8.1f us %6.1f TF  (%.3f)\n", n, t16 / 3 * 1e6,
+             2.0 * n * 256 * 768 / (t16 / 3) / 1e12, t32x / 3 * 1e6, 2.0 * n * 256 * 768 / (t32x / 3) / 1e12, t16 / t32x);
+      std::vector<float> ya((size_t)n * 768), yb(ya.size());
+      rp_lin_shape16 = 1;
+      launch_rp_lin_pipelined<EPI_BIAS>(g, n, sp, st);
+      CK(hipMemcpy(ya.data(), q, ya.size() * 4, hipMemcpyDeviceToHost));
+      rp_lin_shape16 = 0;
+      launch_rp_lin_pipelined<EPI_BIAS>(g, n, sp, st);
+      CK(hipMemcpy(yb.data(), q, ya.size() * 4, hipMemcpyDeviceToHost));
+      rp_lin_shape16 = 1;
+      double mx = 0, ref = 0;
+      for (size_t i = 0; i < ya.size(); ++i) {
+        mx = fmax(mx, fabs((double)ya[i] - (double)yb[i]));
+        ref = fmax(ref, fabs((double)yb[i]));
+      }
+      printf("  outputs: max |diff| %.3g against max |y| %.3g\n", mx, ref);
     }
   }
   if (want('o')) {  // O-proj RESID
