@@ -104,6 +104,16 @@ int st_scorer_embed(const StScorerWeights* w, const float* x, float* z, int n, i
 #define ST_F_NOT_NLL 1        /* --not_nll       (siamese_contrastive.py:424-436) */
 #define ST_F_SIMPLEST 2       /* --simplest_siamese (:384-400): no Predictor       */
 #define ST_F_JUST_USE_ONE 4   /* --just_use_one  (:449-452)                        */
+/* --victim_optimizer (siamese_contrastive.py:780: getattr(optim, name)([ori_latent], lr=lr), torch defaults otherwise),
+ * bits 8..11 of flags; adam_m / adam_v are the rule's two state arrays (both zero at the start).                      */
+#define ST_F_OPT_SHIFT 8
+#define ST_F_OPT_MASK (15 << ST_F_OPT_SHIFT)
+#define ST_OPT_ADAM 0      /* betas (0.9, 0.999), eps 1e-8                                         */
+#define ST_OPT_SGD 1       /* x -= lr g                                                            */
+#define ST_OPT_ADAMW 2     /* Adam with decoupled weight decay 0.01                                */
+#define ST_OPT_ADAMAX 3    /* m, u = max(0.999 u, |g| + 1e-8); x -= lr / (1 - 0.9^t) m / u          */
+#define ST_OPT_RMSPROP 4   /* v = 0.99 v + 0.01 g^2; x -= lr g / (sqrt(v) + 1e-8)                   */
+#define ST_OPT_ADAGRAD 5   /* s += g^2; x -= lr g / (sqrt(s) + 1e-10)                               */
 
 /* One edit iteration for B sentences (replaces get_contrastive_loss + `loss=-(loss); zero_grad();
  * loss.backward(); ori_optimizer.step()`, siamese_contrastive.py:796-810, with torch.optim.Adam

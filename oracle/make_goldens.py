@@ -238,6 +238,12 @@ if __name__ == "__main__":
         sub = [0, 1, 2, 3, 500, 501, 502, 503]
         run_attack(sub, dict(dance=True, not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "dance_notnll", a.threads)
         run_attack(sub, dict(dance=True), ckpt, "dance_nll", a.threads)
+    elif a.what == "optimizers":
+        # --victim_optimizer: the reference takes any torch.optim name with its defaults (siamese_contrastive.py:780).
+        # Learning rates chosen so that each rule moves the latent visibly within 18 iterations.
+        sub = [0, 1, 500, 501]
+        for name, lr in (("SGD", 200.0), ("AdamW", 0.2), ("Adamax", 0.2), ("RMSprop", 0.05), ("Adagrad", 0.5)):
+            run_attack(sub, dict(not_nll=True, victim_optimizer=name, pos_victim_lr=lr, neg_victim_lr=lr), ckpt, "opt_" + name.lower(), a.threads)
     elif a.what == "variants":
         sub = [0, 1, 2, 500, 501, 502]
         if not os.path.exists(os.path.join(GOLD, "attack_nll.npz")):

@@ -291,6 +291,50 @@ class Adam:
         return (x - F32(self.lr / bc1) * (self.m / denom)).astype(F32)
 
 
+class _Rule:
+    """the other torch.optim rules --victim_optimizer can name (single tensor, torch defaults apart from lr)"""
+
+    def __init__(self, shape, lr):
+        self.m = np.zeros(shape, F32)
+        self.v = np.zeros(shape, F32)
+        self.t = 0
+        self.lr = lr
+
+
+class SGD(_Rule):
+    def step(self, x, g):
+        return (x - F32(self.lr) * g).astype(F32)
+
+
+class AdamW(Adam):
+    def step(self, x, g):          # torch.optim.AdamW: param.mul_(1 - lr * weight_decay), weight_decay 0.01, then Adam
+        return Adam.step(self, (x * F32(1.0 - self.lr * 0.01)).astype(F32), g)
+
+
+class Adamax(_Rule):
+    def step(self, x, g):          # betas (0.9, 0.999), eps 1e-8
+        self.t += 1
+        self.m = (self.m + F32(0.1) * (g - self.m)).astype(F32)
+        self.v = np.maximum(self.v * F32(0.999), np.abs(g) + F32(1e-8)).astype(F32)
+        clr = F32(self.lr / (1 - 0.9 ** self.t))
+        return (x - clr * (self.m / self.v)).astype(F32)
+
+
+class RMSprop(_Rule):
+    def step(self, x, g):          # alpha 0.99, eps 1e-8, no momentum
+        self.v = (self.v * F32(0.99) + F32(0.01) * g * g).astype(F32)
+        return (x - F32(self.lr) * (g / (np.sqrt(self.v) + F32(1e-8)))).astype(F32)
+
+
+class Adagrad(_Rule):
+    def step(self, x, g):          # eps 1e-10, no lr decay
+        self.v = (self.v + g * g).astype(F32)
+        return (x - F32(self.lr) * (g / (np.sqrt(self.v) + F32(1e-10)))).astype(F32)
+
+
+OPTIMIZERS = {"Adam": Adam, "SGD": SGD, "AdamW": AdamW, "Adamax": Adamax, "RMSprop": RMSprop, "Adagrad": Adagrad}
+
+
 # ------------------------------------------------------------------------------------------------
 # data.py / attack driver
 # ------------------------------------------------------------------------------------------------
@@ -327,11 +371,11 @@ def headline(s, tok="*"):
 
 def attack_one(ae_sd, ssd, psd, ori_latent, like_latent, unlike_latent, lr, id_to_word, log, tau=0.1,
                not_nll=False, simplest=False, just_use_one=False, max_iter=18, max_change=7, max_len=60,
-               decode=None, trace=None):
+               decode=None, trace=None, optimizer="Adam"):
     """contrastive_attack_one (siamese_contrastive.py:754-839) without --retext/--dance."""
     decode = decode or (lambda lat: greedy_decode(ae_sd, lat, max_len, early_exit=True))
     x = ori_latent.copy()
-    opt = Adam(x.shape, lr)
+    opt = OPTIMIZERS[optimizer](x.shape, lr)
     cur_text = id2text_sentence(decode(x)[0], id_to_word)
     log(headline("", "-"))
     k = 0

@@ -168,8 +168,10 @@ class LeanRecord:
 
 class AttackRunner:
     def __init__(self, ae, scorer, cfg: AttackConfig, device):
-        if cfg.victim_optimizer != "Adam":
-            raise NotImplementedError("--victim_optimizer %s: only Adam has a kernel (the reference default, main.py:100)" % cfg.victim_optimizer)
+        from ._lib import ST_OPTIMIZERS
+        if cfg.victim_optimizer not in ST_OPTIMIZERS:     # the reference: getattr(optim, name), any torch.optim class (:780)
+            raise NotImplementedError("--victim_optimizer %s: the edit-step kernel has %s (torch defaults apart from lr)"
+                                      % (cfg.victim_optimizer, ", ".join(ST_OPTIMIZERS)))
         self.ae, self.scorer, self.cfg, self.device = ae, scorer, cfg, device
         self.ws = ops.DecodeWorkspace(device)
         self.canon = None
@@ -310,7 +312,7 @@ class AttackRunner:
                     out = ops.scorer_edit_step(self.scorer, ori, m, v, like_z, unlike_z, lr, step, mask, tau=c.tau,
                                                not_nll=c.not_nll, simplest=c.simplest_siamese,
                                                just_use_one=c.just_use_one, want_loss=c.want_trace or c.dance,
-                                               want_grad=c.want_trace, want_scores=c.dance)
+                                               want_grad=c.want_trace, want_scores=c.dance, optimizer=c.victim_optimizer)
                     loss, grad = out[0], out[1]
                     if c.dance:
                         dance_rec.append((loss.cpu().numpy(), out[2].cpu().numpy()))

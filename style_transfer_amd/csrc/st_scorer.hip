@@ -261,21 +261,42 @@ __global__ __launch_bounds__(64 * SC_NW) void scorer_kernel(ScorerArgs a) {
       if (a.grad_out) *(f32x4*)(a.grad_out + (size_t)b * 256 + lane * 4) = g;
       if (a.active && !a.active[b]) continue;
       const int t = a.step[b] + 1;
-      const double bc1 = 1.0 - pow(0.9, (double)t);
-      const double bc2 = 1.0 - pow(0.999, (double)t);
-      const float step_size = (float)((double)a.lr[b] / bc1);
-      const float bc2s = (float)sqrt(bc2);
+      const int opt = (a.flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT;
       f32x4 m = *(const f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4);
       f32x4 v = *(const f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4);
       f32x4 x = *(const f32x4*)(a.latent + (size_t)b * 256 + lane * 4);
-      m = m + 0.1f * (g - m);
-      v = v * 0.999f + (0.001f * g) * g;
-      f32x4 den;
-      den.x = sqrtf(v.x) / bc2s + 1e-8f;
-      den.y = sqrtf(v.y) / bc2s + 1e-8f;
-      den.z = sqrtf(v.z) / bc2s + 1e-8f;
-      den.w = sqrtf(v.w) / bc2s + 1e-8f;
-      x = x - step_size * (m / den);
+      const float lr = a.lr[b];
+      if (opt == ST_OPT_ADAM || opt == ST_OPT_ADAMW) {
+        const double bc1 = 1.0 - pow(0.9, (double)t);
+        const double bc2 = 1.0 - pow(0.999, (double)t);
+        const float step_size = (float)((double)lr / bc1);
+        const float bc2s = (float)sqrt(bc2);
+        if (opt == ST_OPT_ADAMW) x = x * (1.0f - lr * 0.01f);  // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first
+        m = m + 0.1f * (g - m);
+        v = v * 0.999f + (0.001f * g) * g;
+        f32x4 den;
+        den.x = sqrtf(v.x) / bc2s + 1e-8f;
+        den.y = sqrtf(v.y) / bc2s + 1e-8f;
+        den.z = sqrtf(v.z) / bc2s + 1e-8f;
+        den.w = sqrtf(v.w) / bc2s + 1e-8f;
+        x = x - step_size * (m / den);
+      } else if (opt == ST_OPT_SGD) {
+        x = x - lr * g;
+      } else if (opt == ST_OPT_ADAMAX) {
+        m = m + 0.1f * (g - m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] * 0.999f, fabsf(g[q]) + 1e-8f);
+        const float clr = (float)((double)lr / (1.0 - pow(0.9, (double)t)));
+        x = x - clr * (m / v);
+      } else if (opt == ST_OPT_RMSPROP) {
+        v = v * 0.99f + (0.01f * g) * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-8f));
+      } else {  // ST_OPT_ADAGRAD
+        v = v + g * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-10f));
+      }
       *(f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4) = m;
       *(f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4) = v;
       *(f32x4*)(a.latent + (size_t)b * 256 + lane * 4) = x;
@@ -327,6 +348,8 @@ extern "C" int st_scorer_edit_step(const StScorerWeights* w, float* latent, floa
   ST_CHECK_ARG((n_pos == 0 || like_z) && (n_neg == 0 || unlike_z), "NULL like_z/unlike_z");
   ST_CHECK_ARG((flags & ST_F_NOT_NLL) || n_pos > 0, "the NLL objective needs n_pos > 0");
   ST_CHECK_ARG(tau > 0.0f, "tau=%g", (double)tau);
+  ST_CHECK_ARG(((flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT) <= ST_OPT_ADAGRAD, "unknown optimizer code %d in flags",
+               (flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT);
   if (!(flags & ST_F_SIMPLEST))
     ST_CHECK_ARG(w->p1_w && w->p1_wt && w->p1_b && w->p2_w && w->p2_wt && w->p2_b, "NULL Predictor weight pointer");
   ScorerArgs a = {};

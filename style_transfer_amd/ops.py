@@ -93,8 +93,11 @@ def scorer_embed(sw, x, unit=True):
 
 
 def scorer_edit_step(sw, latent, adam_m, adam_v, like_z, unlike_z, lr, step, active, tau=0.1, not_nll=False,
-                     simplest=False, just_use_one=False, want_loss=False, want_grad=False, want_scores=False):
-    """-> (loss, grad), or (loss, grad, scores [B, n_pos + n_neg]) with want_scores."""
+                     simplest=False, just_use_one=False, want_loss=False, want_grad=False, want_scores=False, optimizer="Adam"):
+    """-> (loss, grad), or (loss, grad, scores [B, n_pos + n_neg]) with want_scores.
+    optimizer: a torch.optim name (siamese_contrastive.py:780) out of _lib.ST_OPTIMIZERS; adam_m / adam_v are its state."""
+    if optimizer not in _lib.ST_OPTIMIZERS:
+        raise NotImplementedError("--victim_optimizer %s: the kernel has %s" % (optimizer, ", ".join(_lib.ST_OPTIMIZERS)))
     B = latent.shape[0]
     _f32(latent, (B, 256)); _f32(adam_m, (B, 256)); _f32(adam_v, (B, 256)); _f32(lr, (B,))
     n_pos = 0 if like_z is None else like_z.shape[1]
@@ -106,7 +109,7 @@ def scorer_edit_step(sw, latent, adam_m, adam_v, like_z, unlike_z, lr, step, act
     assert step.dtype == torch.int32 and step.is_cuda
     assert active is None or (active.dtype == torch.uint8 and active.is_cuda)
     flags = (_lib.ST_F_NOT_NLL if not_nll else 0) | (_lib.ST_F_SIMPLEST if simplest else 0) | \
-            (_lib.ST_F_JUST_USE_ONE if just_use_one else 0)
+            (_lib.ST_F_JUST_USE_ONE if just_use_one else 0) | (_lib.ST_OPTIMIZERS[optimizer] << _lib.ST_F_OPT_SHIFT)
     loss = torch.empty(B, dtype=torch.float32, device=latent.device) if want_loss else None
     grad = torch.empty(B, 256, dtype=torch.float32, device=latent.device) if want_grad else None
     scores = torch.empty(B, n_pos + n_neg, dtype=torch.float32, device=latent.device) if want_scores else None

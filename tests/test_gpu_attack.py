@@ -110,6 +110,22 @@ def test_attack_variants_match_reference(env, tag, flags, kw):
     assert n_div == 0, report
 
 
+@pytest.mark.parametrize("name,lr", [("SGD", 200.0), ("AdamW", 0.2), ("Adamax", 0.2), ("RMSprop", 0.05), ("Adagrad", 0.5)])
+def test_other_victim_optimizers_match_reference(env, name, lr):
+    """--victim_optimizer other than Adam (siamese_contrastive.py:780 takes any torch.optim name): latents at every iteration,
+    decodes and change counts against the reference's own run with that rule."""
+    g = gold("attack_opt_%s.npz" % name.lower())
+    data, res = run(env, g, not_nll=True, victim_optimizer=name, pos_victim_lr=lr, neg_victim_lr=lr)
+    n_div, report = check_against_golden(res, g)
+    assert n_div == 0, report
+
+
+def test_unknown_victim_optimizer_is_refused(env):
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    with pytest.raises(NotImplementedError, match="LBFGS"):
+        AttackRunner(env["ae"], env["scorer"], AttackConfig(victim_optimizer="LBFGS"), env["dev"])
+
+
 def test_log_is_byte_identical_to_reference(env, gold_notnll, tmp_path):
     """The per-sentence block of the log (Sentence Pair / Src / Rec / Sim / Ref / Change / iteration
     lines) equals the reference's log, and the get_i_iter.py extraction (--pos_c=2 --neg_c=2) of both agree."""

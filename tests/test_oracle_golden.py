@@ -36,6 +36,28 @@ def test_scorer_loss_grad_adam(scorer_sd, tag, kw):
             assert np.abs(x[0] - g["latent"][s, it]).max() < 1e-5 * np.abs(g["latent"][s, it]).max()
 
 
+OPT_LR = {"SGD": 200.0, "AdamW": 0.2, "Adamax": 0.2, "RMSprop": 0.05, "Adagrad": 0.5}
+
+
+@pytest.mark.parametrize("name", list(OPT_LR))
+def test_other_victim_optimizers_match_torch(scorer_sd, name):
+    """--victim_optimizer: the reference builds getattr(optim, name)([latent], lr=lr) (siamese_contrastive.py:780); goldens are its
+    own attack_contrastive runs with each rule (oracle/make_goldens.py --what optimizers).  Fed the reference's gradients, the
+    numpy rules must reproduce the reference's latents."""
+    g = gold("attack_opt_%s.npz" % name.lower())
+    ssd, psd = scorer_sd
+    for s in range(len(g["subset"])):
+        x = g["init_latent"][s:s + 1]
+        assert abs(float(g["lr"][s]) - OPT_LR[name]) < 1e-6
+        opt = O.OPTIMIZERS[name]((1, 256), float(g["lr"][s]))
+        for it in range(int(g["n_iter"][s])):
+            loss, grad = O.contrastive_loss_and_grad(ssd, psd, x, g["like_latent"][s], g["unlike_latent"][s], 0.1, not_nll=True)
+            assert abs(loss - g["loss"][s, it]) < 2e-5 * max(1, abs(g["loss"][s, it]))
+            x = opt.step(x, g["grad"][s:s + 1, it])
+            assert np.abs(x[0] - g["latent"][s, it]).max() < 1e-5 * np.abs(g["latent"][s, it]).max(), (name, s, it)
+        assert np.abs(g["latent"][s, int(g["n_iter"][s]) - 1] - g["init_latent"][s]).max() > 1e-3      # the rule really moved it
+
+
 def test_greedy_decode_kv_cache_matches_reference(ae_sd, gold_notnll):
     g = gold_notnll
     lat = np.concatenate([g["init_latent"][:12], g["latent"][0, :int(g["n_iter"][0])], g["latent"][40, :int(g["n_iter"][40])]])
