@@ -35,6 +35,22 @@
 
 #define RP_LDS ((64 * ST_LDA + 8 * 64 * 4) * 4)
 
+// Kernel-form switches (per translation unit).  tools/kbench.cpp flips them for its A/B runs; for whole-bench comparisons
+// on one box they can be set from the environment (never in production): ST_AB_TAIL32 = the round-1 32x32x16 half-layer
+// kernel, ST_AB_TAIL_ONE_PANEL = one workgroup per panel instead of the persistent loop, ST_AB_LIN32 = the 32x32x16 QKV kernel.
+static int rp_lin_shape16 = 1;
+static int rp_tail_persistent = 1;
+static int rp_tail_shape16 = 1;
+static inline void rp_ab_env() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (getenv("ST_AB_TAIL32")) rp_tail_shape16 = 0;
+  if (getenv("ST_AB_TAIL_ONE_PANEL")) rp_tail_persistent = 0;
+  if (getenv("ST_AB_LIN32")) rp_lin_shape16 = 0;
+}
+
+
 // store 4 consecutive features of a panel row (feature index c = 4*c4) in the kernel's operand format.
 // f16x3: a value outside the f16 range (or NaN) would turn into inf - inf = NaN inside the products and come
 // out as a silent garbage argmax, so it raises *flag instead (checked by the host entry point: ST_ERANGE).
@@ -887,11 +903,11 @@ __global__ __launch_bounds__(256, 2) void rp_lin16_kernel(GemmArgs a) {
   }
   if (bad && a.range_flag) *a.range_flag = 1;
 }
-static int rp_lin_shape16 = 1;  // tools/kbench.cpp flips it for the A/B
 template <int EPI>
 static int launch_rp_lin_pipelined(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   ST_ENSURE_LDS((rp_lin_kernel<EPI>), RP_LDS);
   ST_ENSURE_LDS((rp_lin16_kernel<EPI>), RP_LDS);
+  rp_ab_env();
   if (n_bound <= 0) return ST_OK;
   const bool aligned = a.N % 32 == 0 && (EPI == EPI_BIAS ? (a.ldo % 4 == 0 && ((size_t)a.out & 15) == 0)
                                                         : (a.kv_stride % 4 == 0 && ((size_t)a.q & 15) == 0 && ((size_t)a.kbase & 15) == 0 &&
@@ -2184,7 +2200,6 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   if (bad && a.range_flag) *a.range_flag = 1;
 }
 
-static int rp_tail_persistent = 1;  // tools/kbench.cpp clears it for the one-panel-per-workgroup A/B
 static inline int st_cu_count() {
   static int cus[16] = {0};
   int dev = 0;
@@ -2209,7 +2224,6 @@ static int launch_layer_tail64(const OFArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
-static int rp_tail_shape16 = 1;  // 1: the 16x16x32 form; tools/kbench.cpp flips it for the A/B
 static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
   ST_ENSURE_LDS((rp_layer_tail16_kernel<0>), RP_TAIL_LDS);
   if (n_bound <= 0) return ST_OK;
@@ -2229,6 +2243,7 @@ static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
 // turnaround phases as intended, but every W fragment feeds three MFMAs instead of six and the doubled L2 -> CU weight
 // stream costs more than the overlap gains.  launch_layer_tail32 stays reachable from tools/kbench.cpp only.
 static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) {
+  rp_ab_env();
   return rp_tail_shape16 ? launch_layer_tail16(a, n_bound, st) : launch_layer_tail64(a, n_bound, st);
 }
 
