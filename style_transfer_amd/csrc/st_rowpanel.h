@@ -37,8 +37,10 @@
 
 // Kernel-form switches (per translation unit).  tools/kbench.cpp flips them for its A/B runs; for whole-bench comparisons
 // on one box they can be set from the environment (never in production): ST_AB_TAIL32 = the round-1 32x32x16 half-layer
-// kernel, ST_AB_TAIL_ONE_PANEL = one workgroup per panel instead of the persistent loop, ST_AB_LIN32 = the 32x32x16 QKV kernel.
+// kernel, ST_AB_TAIL_ONE_PANEL = one workgroup per panel instead of the persistent loop, ST_AB_LIN32 = the 32x32x16 QKV kernel,
+// ST_AB_SCREEN32 = the 32x32x16 screening pass.
 static int rp_lin_shape16 = 1;
+static int rp_screen_shape16 = 1;
 static int rp_tail_persistent = 1;
 static int rp_tail_shape16 = 1;
 static inline void rp_ab_env() {
@@ -48,6 +50,7 @@ static inline void rp_ab_env() {
   if (getenv("ST_AB_TAIL32")) rp_tail_shape16 = 0;
   if (getenv("ST_AB_TAIL_ONE_PANEL")) rp_tail_persistent = 0;
   if (getenv("ST_AB_LIN32")) rp_lin_shape16 = 0;
+  if (getenv("ST_AB_SCREEN32")) rp_screen_shape16 = 0;
 }
 
 
@@ -575,6 +578,210 @@ __global__ __launch_bounds__(256, 2) void rp_screen_kernel(GemmArgs a) {
     a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, rownorm[tid]);
   }
 }
+// ------------------------------------------------------------------------------------------------
+// The screening pass on v_mfma_f32_16x16x32_f16 tiles with W as the A operand (see rp_layer_tail16_kernel for the lane
+// addressing of the unchanged packed image; the panel keeps its hi-halves-only layout).  Lane (r16, g) holds the logits
+// of vocabulary columns 32 blk + 16 ft + 4 g + i of panel row 16 rt + r16: a row's candidates live in 8 key slots of 4
+// lanes, so the final top-2 merge is local plus two lane exchanges per row tile (the 32x32x16 form: five exchanges
+// for each of 32 slots).
+// ------------------------------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256, 2) void rp_screen16_kernel(GemmArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                  // [64][RS_LDA]
+  float* red = smem + 64 * RS_LDA;   // [4 waves][64 rows][4]
+  float* rownorm = red + 4 * 64 * 4; // [64]
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  {
+    // one wave per row, 16 rows each: global -> registers -> LayerNorm -> hi halves in LDS
+    f32x4 ga = {1, 1, 1, 1}, gb = {0, 0, 0, 0};
+    if (a.ln_a) {
+      ga = *(const f32x4*)(a.ln_a + lane * 4);
+      gb = *(const f32x4*)(a.ln_b + lane * 4);
+    }
+    f32x4 v[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = min(m0 + wave * 16 + rr, n - 1);
+      v[rr] = *(const f32x4*)(a.X + (size_t)(a.xrows ? a.xrows[r] : r) * 256 + lane * 4);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = wave * 16 + rr;
+      f32x4 y = v[rr];
+      float nrm = INFINITY;  // no LayerNorm, no norm: every row counts as ambiguous
+      if (a.ln_a) {
+        y = layernorm256r(y, ga, gb);
+        nrm = sqrtf(wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w));
+      }
+      if (lane == 0) rownorm[r] = nrm;
+      const float m = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+      bad |= !(m <= 65504.0f);
+      h4 hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi[j] = (_Float16)y[j];
+      *(h4*)((_Float16*)(As + r * RS_LDA) + lane * 4) = hi;
+    }
+    if (bad && a.range_flag) *a.range_flag = 1;
+  }
+  __syncthreads();
+
+  // running (best, second) keys per (feature tile, row tile, register): start below every finite logit
+  float k1[2][4][4], k2[2][4][4];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) k1[ft][rt][q] = k2[ft][rt][q] = -INFINITY;
+  const int nblk = (a.N + 31) >> 5;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;  // column split blockIdx.y covers blocks [b0, b1)
+  const int b0 = blockIdx.y * per;
+  const int b1 = min(nblk, b0 + per);
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) / 4 : 0;  // this wave's blocks: b0 + wave, b0 + wave + 4, ...
+  const f32x4* Wl = (const f32x4*)a.W + (g >> 1) * 128 + 32 * (g & 1) + r16;
+  const float* Ab = As + r16 * RS_LDA + 4 * g;
+  auto wbase = [&](int i) -> const f32x4* { return Wl + (size_t)(b0 + wave + 4 * min(i, cnt - 1)) * 16 * 128; };
+  auto book = [&](float v, int i, float& b1, float& b2) {  // 3 VALU operations
+    const float key = __int_as_float((__float_as_int(v) & ~0xff) | i);
+    b2 = __builtin_amdgcn_fmed3f(b1, key, b2);
+    b1 = fmaxf(b1, key);
+  };
+  f32x4 rw[4][2];  // W ring, four double steps deep: [slot][ft] (hi fragments only)
+  if (cnt > 0) {
+    const f32x4* W0 = wbase(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rw[j][0] = W0[j * 256];
+      rw[j][1] = W0[j * 256 + 16];
+    }
+  }
+  f32x4 pn[2];  // panel fragments (hi) of the next half-step: row tiles 2hf, 2hf + 1
+  pn[0] = *(const f32x4*)(Ab);
+  pn[1] = *(const f32x4*)(Ab + 16 * RS_LDA);
+  // one block: 8 double k-steps into acc; meanwhile the previous block's accumulators (o; block number io) are booked,
+  // two logits per half-step
+  auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_book) {
+    const f32x4* Wb = wbase(i);
+    const f32x4* Wn = wbase(i + 1);
+    {
+      const int col = ((b0 + wave + 4 * i) << 5) + 4 * g;
+      f32x4 bv[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cc = col + 16 * ft + q;
+          bv[ft][q] = cc < a.N ? (a.bias ? a.bias[cc] : 0.0f) : RS_PAD_LOGIT;
+        }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[0][rt] = bv[0];
+        acc[1][rt] = bv[1];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int sl = d & 3;
+      const h8 w0 = as_h8(rw[sl][0]), w1 = as_h8(rw[sl][1]);
+      {
+        const f32x4* Wx = d + 4 < 8 ? Wb + (d + 4) * 256 : Wn + (d + 4 - 8) * 256;
+        rw[sl][0] = Wx[0];
+        rw[sl][1] = Wx[16];
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const h8 p0 = as_h8(pn[0]), p1 = as_h8(pn[1]);
+        {
+          const int nd = hf ? ((d + 1) & 7) : d, nrt = hf ? 0 : 2;
+          const float* q = Ab + nrt * 16 * RS_LDA + 16 * nd;
+          pn[0] = *(const f32x4*)(q);
+          pn[1] = *(const f32x4*)(q + 16 * RS_LDA);
+        }
+        const int rt = 2 * hf;
+        acc[0][rt] = mfma16x32h(w0, p0, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(w1, p0, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(w0, p1, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(w1, p1, acc[1][rt + 1]);
+        if (do_book) {  // half-step u = 2d + hf books slot (ft, rt', q-pair): 16 half-steps x 2 logits = 32
+          const int u = 2 * d + hf;
+          const int ft = u & 1, rtb = (u >> 1) & 3, qp = u >> 3;  // registers 2 qp, 2 qp + 1
+          book(o[ft][rtb][2 * qp], io, k1[ft][rtb][2 * qp], k2[ft][rtb][2 * qp]);
+          book(o[ft][rtb][2 * qp + 1], io, k1[ft][rtb][2 * qp + 1], k2[ft][rtb][2 * qp + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto book_all = [&](const f32x4 (&o)[2][4], int io) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) book(o[ft][rt][q], io, k1[ft][rt][q], k2[ft][rt][q]);
+  };
+  f32x4 A[2][4], B[2][4];
+  if (cnt > 0) {
+    block(A, 0, A, 0, false);
+    int i = 1;
+    for (; i + 1 < cnt; i += 2) {
+      block(B, i, A, i - 1, true);
+      block(A, i + 1, B, i, true);
+    }
+    if (i < cnt) {  // an even number of blocks: one more into B, then book B
+      block(B, i, A, i - 1, true);
+      book_all(B, i);
+    } else {
+      book_all(A, cnt - 1);
+    }
+  }
+  // keys -> (value, column, second): the 8 slots of a lane, then the 4 lanes (g) of a row, then the 4 waves through LDS
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Top2 u;
+        u.m1 = k1[ft][rt][q];
+        u.i1 = ((b0 + wave + 4 * (__float_as_int(u.m1) & 0xff)) << 5) + 16 * ft + 4 * g + q;
+        u.m2 = k2[ft][rt][q];
+        t = top2_merge(t, u);
+      }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      Top2 u;
+      u.m1 = __shfl_xor(t.m1, o, 64);
+      u.i1 = __shfl_xor(t.i1, o, 64);
+      u.m2 = __shfl_xor(t.m2, o, 64);
+      t = top2_merge(t, u);
+    }
+    if (g == 0) {
+      float* p = red + (wave * 64 + 16 * rt + r16) * 4;
+      p[0] = t.m1;
+      p[1] = __int_as_float(t.i1);
+      p[2] = t.m2;
+    }
+  }
+  __syncthreads();
+  if (tid < 64 && m0 + tid < n) {
+    Top2 t = {red[tid * 4 + 0], __float_as_int(red[tid * 4 + 1]), red[tid * 4 + 2]};
+    for (int w = 1; w < 4; ++w) {
+      Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
+      t = top2_merge(t, u);
+    }
+    // keys sit up to 2^-15 |v| off their logits: finish_kernel's margin has a term for that
+    a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, rownorm[tid]);
+  }
+}
 // grid (panels, column splits); needs ceil(N / 128) <= RS_MAX_BLOCKS (the block number must fit the 8 key bits)
 static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   ST_ENSURE_LDS((rp_screen_kernel<0>), RS_LDS);
@@ -583,7 +790,13 @@ static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, int splits
     st_set_error("rp_screen: needs the f16x3 format and N <= %d (N=%d)", RS_MAX_BLOCKS * 128, a.N);
     return ST_EINVAL;
   }
-  hipLaunchKernelGGL((rp_screen_kernel<0>), dim3((n_bound + 63) / 64, splits), dim3(256), RS_LDS, st, a);
+  rp_ab_env();
+  if (rp_screen_shape16) {
+    ST_ENSURE_LDS((rp_screen16_kernel<0>), RS_LDS);
+    hipLaunchKernelGGL((rp_screen16_kernel<0>), dim3((n_bound + 63) / 64, splits), dim3(256), RS_LDS, st, a);
+  } else {
+    hipLaunchKernelGGL((rp_screen_kernel<0>), dim3((n_bound + 63) / 64, splits), dim3(256), RS_LDS, st, a);
+  }
   ST_LAUNCH_CHECK();
   return ST_OK;
 }

@@ -150,8 +150,30 @@ int main(int argc, char** argv) {
     g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
     const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(n, V, 16);
-    t = timeit([&] { launch_rp_screen_pipelined(g, n, sp, st); });
-    printf("gen screen, pipelined bookkeeping n=%d: %8.1f us %6.1f TF (one product)\n", n, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
+    double t16 = 0, t32x = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      rp_screen_shape16 = 1;
+      t16 += timeit([&] { launch_rp_screen_pipelined(g, n, sp, st); }, 5);
+      rp_screen_shape16 = 0;
+      t32x += timeit([&] { launch_rp_screen_pipelined(g, n, sp, st); }, 5);
+    }
+    printf("gen screen n=%d splits=%d: 16x16x32 %8.1f us %6.1f TF   32x32x16 %8.1f us %6.1f TF (one product)  (%.3f)\n", n, sp, t16 / 3 * 1e6,
+           2.0 * n * 256 * V / (t16 / 3) / 1e12, t32x / 3 * 1e6, 2.0 * n * 256 * V / (t32x / 3) / 1e12, t16 / t32x);
+    std::vector<float4> pa((size_t)n * sp), pb(pa.size());
+    rp_screen_shape16 = 1;
+    launch_rp_screen_pipelined(g, n, sp, st);
+    CK(hipMemcpy(pa.data(), partial, pa.size() * 16, hipMemcpyDeviceToHost));
+    rp_screen_shape16 = 0;
+    launch_rp_screen_pipelined(g, n, sp, st);
+    CK(hipMemcpy(pb.data(), partial, pb.size() * 16, hipMemcpyDeviceToHost));
+    rp_screen_shape16 = 1;
+    size_t di = 0;
+    double dm = 0;
+    for (size_t i = 0; i < pa.size(); ++i) {
+      di += memcmp(&pa[i].y, &pb[i].y, 4) != 0;
+      dm = fmax(dm, fmax(fabs((double)pa[i].x - pb[i].x), fabs((double)pa[i].z - pb[i].z)));
+    }
+    printf("  partials: %zu of %zu best columns differ, max |best / second difference| %.3g\n", di, pa.size(), dm);
   }
   if (want('f')) {  // FFN1 (rp RELU)
     GemmArgs g = {};
