@@ -18,6 +18,7 @@
 // on the host (tests replay them through the CPU restatement).
 #include <math.h>
 
+#include <algorithm>
 #include "st_common.h"
 
 #ifndef ST_TRY
@@ -63,65 +64,119 @@ struct GArgs {
   long sai, sar, sbr, sbj;
   int ldc, accumulate;
 };
-#define AG_LD 68
-__global__ __launch_bounds__(256) void ae_gemm_kernel(GArgs a) {
-  __shared__ float As[16][AG_LD], Bs[16][AG_LD];
+#define AG_LDW 36  /* operand row stride in LDS: 32 contraction steps + 4 (conflict-free 16-byte fragment reads) */
+// 128 x 128 tile per workgroup, 64 x 64 per wave (2 x 2 exact-f32 MFMA tiles), contraction in steps of 32 through LDS
+// with the next step's operands prefetched into registers.  Operand strides are arguments (one kernel serves
+// Y = X W^T, dX = dY W and dW = dY^T X); loads are scalar and coalesced along whichever index is contiguous.
+// gridDim.z > 1: split over the contraction index, slice z writes its partial product to slab + z * M * N (no bias, no
+// accumulate) and ae_slab_sum_kernel adds the slices in a fixed order (weight gradients contract over ~10^4 rows into
+// a few hundred output tiles: without the split a handful of CUs would run the whole product).
+__global__ __launch_bounds__(256) void ae_gemm_kernel(GArgs a, float* __restrict__ slab, int r_per_slice) {
+  __shared__ __align__(16) float As[128 * AG_LDW], Bs[128 * AG_LDW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  const int r_lo = blockIdx.z * r_per_slice, r_hi = min(a.R, r_lo + r_per_slice);
   const bool a_r_fast = a.sar == 1, b_r_fast = a.sbr == 1;
-  float ra[4], rb[4];
+  float ra[16], rb[16];
   auto fetch = [&](int rc) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 16; ++q) {
       const int e = tid + 256 * q;
-      const int ar = a_r_fast ? (e & 15) : (e >> 6), ai = a_r_fast ? (e >> 4) : (e & 63);
-      const int br = b_r_fast ? (e & 15) : (e >> 6), bj = b_r_fast ? (e >> 4) : (e & 63);
-      ra[q] = (i0 + ai < a.M && rc + ar < a.R) ? a.A[(long)(i0 + ai) * a.sai + (long)(rc + ar) * a.sar] : 0.0f;
-      rb[q] = (j0 + bj < a.N && rc + br < a.R) ? a.B[(long)(rc + br) * a.sbr + (long)(j0 + bj) * a.sbj] : 0.0f;
+      const int ar = a_r_fast ? (e & 31) : (e >> 7), ai = a_r_fast ? (e >> 5) : (e & 127);
+      const int br = b_r_fast ? (e & 31) : (e >> 7), bj = b_r_fast ? (e >> 5) : (e & 127);
+      ra[q] = (i0 + ai < a.M && rc + ar < r_hi) ? a.A[(long)(i0 + ai) * a.sai + (long)(rc + ar) * a.sar] : 0.0f;
+      rb[q] = (j0 + bj < a.N && rc + br < r_hi) ? a.B[(long)(rc + br) * a.sbr + (long)(j0 + bj) * a.sbj] : 0.0f;
     }
   };
-  f32x16 acc;
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32, l31 = lane & 31, half = lane >> 5;
-  if (a.R > 0) fetch(0);
-  for (int rc = 0; rc < a.R; rc += 16) {
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, half = lane >> 5;
+  if (r_lo < r_hi) fetch(r_lo);
+  for (int rc = r_lo; rc < r_hi; rc += 32) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 16; ++q) {
       const int e = tid + 256 * q;
-      const int ar = a_r_fast ? (e & 15) : (e >> 6), ai = a_r_fast ? (e >> 4) : (e & 63);
-      const int br = b_r_fast ? (e & 15) : (e >> 6), bj = b_r_fast ? (e >> 4) : (e & 63);
-      As[ar][ai] = ra[q];
-      Bs[br][bj] = rb[q];
+      const int ar = a_r_fast ? (e & 31) : (e >> 7), ai = a_r_fast ? (e >> 5) : (e & 127);
+      const int br = b_r_fast ? (e & 31) : (e >> 7), bj = b_r_fast ? (e >> 5) : (e & 127);
+      As[ai * AG_LDW + ar] = ra[q];
+      Bs[bj * AG_LDW + br] = rb[q];
     }
     __syncthreads();
-    if (rc + 16 < a.R) fetch(rc + 16);
+    if (rc + 32 < r_hi) fetch(rc + 32);
+    const float* Ab = As + (wr * 64 + l31) * AG_LDW + 4 * half;
+    const float* Bb = Bs + (wc * 64 + l31) * AG_LDW + 4 * half;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) acc = mfma32(As[2 * kk + half][wi + l31], Bs[2 * kk + half][wj + l31], acc);
-  }
-  const int j = j0 + wj + l31;
-  const float bj = (a.bias && j < a.N) ? a.bias[j] : 0.0f;
+    for (int kg = 0; kg < 4; ++kg) {
+      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8), a1 = *(const f32x4*)(Ab + 32 * AG_LDW + kg * 8);
+      const f32x4 b0 = *(const f32x4*)(Bb + kg * 8), b1 = *(const f32x4*)(Bb + 32 * AG_LDW + kg * 8);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = i0 + wi + mfma32_row(r, lane);
-    if (i < a.M && j < a.N) {
-      float* c = a.C + (long)i * a.ldc + j;
-      *c = (a.accumulate ? *c : 0.0f) + acc[r] + bj;
+      for (int q = 0; q < 4; ++q) {
+        acc[0][0] = mfma32(a0[q], b0[q], acc[0][0]);
+        acc[0][1] = mfma32(a0[q], b1[q], acc[0][1]);
+        acc[1][0] = mfma32(a1[q], b0[q], acc[1][0]);
+        acc[1][1] = mfma32(a1[q], b1[q], acc[1][1]);
+      }
     }
   }
+  const bool sliced = gridDim.z > 1;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int j = j0 + wc * 64 + ni * 32 + l31;
+      if (j >= a.N) continue;
+      const float bj = (a.bias && !sliced) ? a.bias[j] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wr * 64 + mi * 32 + mfma32_row(r, lane);
+        if (i >= a.M) continue;
+        if (sliced) {
+          slab[((size_t)blockIdx.z * a.M + i) * a.N + j] = acc[mi][ni][r];
+        } else {
+          float* c = a.C + (long)i * a.ldc + j;
+          *c = (a.accumulate ? *c : 0.0f) + acc[mi][ni][r] + bj;
+        }
+      }
+    }
+}
+// C[i][j] = (accumulate ? C : 0) + bias[j] + sum_z slab[z][i][j], slices added in index order
+__global__ __launch_bounds__(256) void ae_slab_sum_kernel(GArgs a, const float* __restrict__ slab, int nz) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)a.M * a.N) return;
+  const int i = (int)(e / a.N), j = (int)(e % a.N);
+  float s = 0.0f;
+  for (int z = 0; z < nz; ++z) s += slab[(size_t)z * a.M * a.N + e];
+  float* c = a.C + (long)i * a.ldc + j;
+  *c = (a.accumulate ? *c : 0.0f) + s + (a.bias ? a.bias[j] : 0.0f);
 }
 
-// column sums: out[c] = sum_rows X[row][c]   (one block per 64 columns; fixed order)
-__global__ __launch_bounds__(256) void ae_colsum_kernel(const float* __restrict__ X, int rows, int N, float* __restrict__ out) {
+// column sums: out[c] = sum_rows X[row][c], in two fixed-order stages: grid (64-column blocks, row slices) -> part[slice][c],
+// then one thread per column adds the slices.  (One workgroup per 64 columns walking all rows was 45 % of the step.)
+#define AE_COLSUM_SLICES 64
+__global__ __launch_bounds__(256) void ae_colsum_kernel(const float* __restrict__ X, int rows, int N, float* __restrict__ part) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rg = threadIdx.x >> 6;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   float s = 0.0f;
   if (c < N)
-    for (int r = rg; r < rows; r += 4) s += X[(long)r * N + c];
+    for (int r = r0 + rg; r < r1; r += 4) s += X[(long)r * N + c];
   red[rg][cl] = s;
   __syncthreads();
-  if (rg == 0 && c < N) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (rg == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+__global__ __launch_bounds__(256) void ae_colsum_finish_kernel(const float* __restrict__ part, int nslices, int N, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.0f;
+  for (int z = 0; z < nslices; ++z) s += part[(size_t)z * N + c];
+  out[c] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,6 +586,7 @@ struct Arena {
 struct LayerSave {
   float *x_in, *n0, *q, *k, *v, *P, *att, *x1, *u, *x2, *n2, *h;  // u / x2: decoder only (source-attention sublayer)
 };
+#define AE_MAX_SLICES 16
 struct Ws {
   // encoder (Re rows), decoder (Rd rows)
   int32_t *e_row_sent, *d_row_sent;
@@ -541,6 +597,8 @@ struct Ws {
   float *sl_loss, *sl_lse, *sl_g, *sl_dori, *sl_dlike, *con_rows;
   void* sl_scratch;
   size_t sl_scratch_bytes;
+  float* slab;          // split-K partial products of the weight-gradient GEMMs
+  size_t slab_floats;
   size_t total;
 };
 
@@ -570,6 +628,8 @@ Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
   w.th = a.f((size_t)R * dff);
   w.sl_loss = a.f(B); w.sl_lse = a.f(B); w.sl_g = a.f(B); w.sl_dori = a.f((size_t)B * 256); w.sl_dlike = a.f((size_t)B * 256);
   w.con_rows = a.f((size_t)(Se / (B > 0 ? B : 1)) * B);
+  w.slab_floats = (size_t)AE_MAX_SLICES * 256 * (dff > 768 ? dff : 768);
+  w.slab = a.f(w.slab_floats);
   w.sl_scratch_bytes = st_simloss_scratch_bytes(B, B);
   w.sl_scratch = base ? base + a.off : nullptr;
   a.off += up256(w.sl_scratch_bytes);
@@ -580,11 +640,32 @@ Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
 struct Ctx {
   hipStream_t st;
   int rc;
+  float* slab;
+  size_t slab_floats;
   int gemm(const float* A, long sai, long sar, const float* Bm, long sbr, long sbj, float* C, int ldc, const float* bias, int M, int N,
            int R, int accumulate) {
     if (M <= 0 || N <= 0) return ST_OK;
     GArgs a{A, Bm, C, bias, M, N, R, sai, sar, sbr, sbj, ldc, accumulate};
-    hipLaunchKernelGGL(ae_gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, a);
+    const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
+    int nz = 1;
+    if (tiles < 128 && R >= 2048 && slab) {  // few output tiles, long contraction: slices of >= 512 steps until ~256 workgroups
+      nz = std::min(std::min(AE_MAX_SLICES, (256 + tiles - 1) / tiles), R / 512);
+      while (nz > 1 && (size_t)nz * M * N > slab_floats) --nz;
+    }
+    const int per = nz > 1 ? (((R + nz - 1) / nz + 31) / 32) * 32 : R;
+    hipLaunchKernelGGL(ae_gemm_kernel, dim3((N + 127) / 128, (M + 127) / 128, nz), dim3(256), 0, st, a, slab, per);
+    if (nz > 1)
+      hipLaunchKernelGGL(ae_slab_sum_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, st, a, (const float*)slab, nz);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
+  int colsum(const float* X, int rows, int N, float* out) {
+    int ns = std::min(AE_COLSUM_SLICES, std::max(1, rows / 64));
+    while (ns > 1 && (size_t)ns * N > slab_floats) --ns;
+    if (!slab) ns = 1;
+    float* part = ns > 1 ? slab : out;
+    hipLaunchKernelGGL(ae_colsum_kernel, dim3((N + 63) / 64, ns), dim3(256), 0, st, X, rows, N, part);
+    if (ns > 1) hipLaunchKernelGGL(ae_colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)part, ns, N, out);
     ST_LAUNCH_CHECK();
     return ST_OK;
   }
@@ -596,10 +677,7 @@ struct Ctx {
   int lin_bwd(const float* dY, const float* X, const float* W, float* dX, int acc_dx, float* dW, float* db, int rows, int N, int K) {
     if (dX) ST_TRY(gemm(dY, N, 1, W, K, 1, dX, K, nullptr, rows, K, N, acc_dx));
     if (dW) ST_TRY(gemm(dY, 1, N, X, K, 1, dW, K, nullptr, N, K, rows, 0));
-    if (db) {
-      hipLaunchKernelGGL(ae_colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, dY, rows, N, db);
-      ST_LAUNCH_CHECK();
-    }
+    if (db) ST_TRY(colsum(dY, rows, N, db));
     return ST_OK;
   }
 };
@@ -635,7 +713,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     st_set_error("st_ae_train_step: workspace too small: need %zu bytes, have %zu", w.total, workspace_bytes);
     return ST_ENOMEM;
   }
-  Ctx c{(hipStream_t)stream, 0};
+  Ctx c{(hipStream_t)stream, 0, w.slab, w.slab_floats};
   const int Re = n_enc_rows, Se = n_enc_sent, Rd = n_dec_rows, L = p->n_layers, dff = p->d_ff, V = p->vocab;
   const int n_views = Se / B - 1;
   auto drop = [&](uint32_t site) { return Drop{seed, drop_p, drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f, site}; };
