@@ -84,6 +84,78 @@ __global__ __launch_bounds__(256) void tg_gemm_kernel(TgArgs a) {
   }
 }
 
+// The same product on a 128 x 128 tile per workgroup (64 x 64 per wave, contraction steps of 32): 4x the MFMA work per
+// LDS byte and per barrier.  Used when it still fills the chip (large batches); the 64 x 64 form above keeps the small ones.
+#define TG_LDW 36
+__global__ __launch_bounds__(256) void tg_gemm128_kernel(TgArgs a) {
+  __shared__ __align__(16) float As[128 * TG_LDW], Bs[128 * TG_LDW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  const int r0 = blockIdx.z * a.rper, r1 = min(a.R, r0 + a.rper);
+  const bool a_r_fast = a.sar == 1, b_r_fast = a.sbr == 1;
+  float ra[16], rb[16];
+  auto fetch = [&](int rc) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = tid + 256 * q;
+      const int ar = a_r_fast ? (e & 31) : (e >> 7), ai = a_r_fast ? (e >> 5) : (e & 127);
+      const int br = b_r_fast ? (e & 31) : (e >> 7), bj = b_r_fast ? (e >> 5) : (e & 127);
+      ra[q] = (i0 + ai < a.M && rc + ar < r1) ? a.A[(long)(i0 + ai) * a.sai + (long)(rc + ar) * a.sar] : 0.0f;
+      rb[q] = (j0 + bj < a.N && rc + br < r1) ? a.B[(long)(rc + br) * a.sbr + (long)(j0 + bj) * a.sbj] : 0.0f;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, half = lane >> 5;
+  if (r0 < r1) fetch(r0);
+  for (int rc = r0; rc < r1; rc += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = tid + 256 * q;
+      const int ar = a_r_fast ? (e & 31) : (e >> 7), ai = a_r_fast ? (e >> 5) : (e & 127);
+      const int br = b_r_fast ? (e & 31) : (e >> 7), bj = b_r_fast ? (e >> 5) : (e & 127);
+      As[ai * TG_LDW + ar] = ra[q];
+      Bs[bj * TG_LDW + br] = rb[q];
+    }
+    __syncthreads();
+    if (rc + 32 < r1) fetch(rc + 32);
+    const float* Ab = As + (wr * 64 + l31) * TG_LDW + 4 * half;
+    const float* Bb = Bs + (wc * 64 + l31) * TG_LDW + 4 * half;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const f32x4 a0 = *(const f32x4*)(Ab + kg * 8), a1 = *(const f32x4*)(Ab + 32 * TG_LDW + kg * 8);
+      const f32x4 b0 = *(const f32x4*)(Bb + kg * 8), b1 = *(const f32x4*)(Bb + 32 * TG_LDW + kg * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[0][0] = mfma32(a0[q], b0[q], acc[0][0]);
+        acc[0][1] = mfma32(a0[q], b1[q], acc[0][1]);
+        acc[1][0] = mfma32(a1[q], b0[q], acc[1][0]);
+        acc[1][1] = mfma32(a1[q], b1[q], acc[1][1]);
+      }
+    }
+  }
+  float* C = a.C + (long)blockIdx.z * a.slab;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int j = j0 + wc * 64 + ni * 32 + l31;
+      if (j >= a.N) continue;
+      const float bj = a.bias ? a.bias[j] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wr * 64 + mi * 32 + mfma32_row(r, lane);
+        if (i < a.M) C[(long)i * a.ldc + j] = acc[mi][ni][r] + bj;
+      }
+    }
+}
+
 // out[e] = sum_s in[s*stride + e]   (fixed order: reproducible)
 __global__ __launch_bounds__(256) void tr_slab_sum_kernel(const float* __restrict__ in, int nslab, long stride, long n,
                                                           float* __restrict__ out) {
@@ -110,29 +182,51 @@ __global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict_
 
 // ---- BatchNorm (train mode), one statistic set per (call g, feature) ----
 // grid (ceil(N/64), G): mean and BIASED variance of H[g*B .. g*B+B, col], two passes
-__global__ __launch_bounds__(256) void tr_bn_stats_kernel(const float* __restrict__ H, int B, int N, float* __restrict__ mean,
-                                                          float* __restrict__ var) {
-  __shared__ float red[4][64];
+// 1024 threads = 64 columns x 16 row groups, two rows in flight per thread: with 4 row groups the kernel walked 8192 rows
+// twice at 0.56 TB/s and was 37 % of the B = 8192 step.
+#define TR_RG 16
+__device__ __forceinline__ float tr_rg_sum(float (*red)[64], int cl) {  // fixed order over the 16 row groups
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < TR_RG; k += 4) s += (red[k][cl] + red[k + 1][cl]) + (red[k + 2][cl] + red[k + 3][cl]);
+  return s;
+}
+__global__ __launch_bounds__(64 * TR_RG) void tr_bn_stats_kernel(const float* __restrict__ H, int B, int N, float* __restrict__ mean,
+                                                                 float* __restrict__ var) {
+  __shared__ float red[TR_RG][64];
   const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rg = threadIdx.x >> 6, g = blockIdx.y;
   const float* Hg = H + (long)g * B * N;
-  float s = 0.0f;
-  if (c < N)
-    for (int r = rg; r < B; r += 4) s += Hg[(long)r * N + c];
-  red[rg][cl] = s;
-  __syncthreads();
-  const float mu = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)B;
-  __syncthreads();
-  float q = 0.0f;
-  if (c < N)
-    for (int r = rg; r < B; r += 4) {
-      const float d = Hg[(long)r * N + c] - mu;
-      q = fmaf(d, d, q);
+  float s0 = 0.0f, s1 = 0.0f;
+  if (c < N) {
+    int r = rg;
+    for (; r + TR_RG < B; r += 2 * TR_RG) {
+      s0 += Hg[(long)r * N + c];
+      s1 += Hg[(long)(r + TR_RG) * N + c];
     }
-  red[rg][cl] = q;
+    if (r < B) s0 += Hg[(long)r * N + c];
+  }
+  red[rg][cl] = s0 + s1;
+  __syncthreads();
+  const float mu = tr_rg_sum(red, cl) / (float)B;
+  __syncthreads();
+  float q0 = 0.0f, q1 = 0.0f;
+  if (c < N) {
+    int r = rg;
+    for (; r + TR_RG < B; r += 2 * TR_RG) {
+      const float d0 = Hg[(long)r * N + c] - mu, d1 = Hg[(long)(r + TR_RG) * N + c] - mu;
+      q0 = fmaf(d0, d0, q0);
+      q1 = fmaf(d1, d1, q1);
+    }
+    if (r < B) {
+      const float d0 = Hg[(long)r * N + c] - mu;
+      q0 = fmaf(d0, d0, q0);
+    }
+  }
+  red[rg][cl] = q0 + q1;
   __syncthreads();
   if (rg == 0 && c < N) {
     mean[(long)g * N + c] = mu;
-    var[(long)g * N + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)B;
+    var[(long)g * N + c] = tr_rg_sum(red, cl) / (float)B;
   }
 }
 // running statistics: G sequential momentum updates in call order (unbiased variance, as nn.BatchNorm1d)
@@ -204,12 +298,12 @@ __device__ __forceinline__ float tr_dy(const BnActArgs& a, long e, int g, int b,
   if (a.drop_p > 0.0f) d = tr_keep(a.mask, a.seed, tr_mask_index(g, a.layer, b, c, a.B, a.N), a.drop_p) ? d * (1.0f / (1.0f - a.drop_p)) : 0.0f;
   return y > 0.0f ? d : a.slope * d;
 }
-__global__ __launch_bounds__(256) void tr_bn_bwd_sums_kernel(BnActArgs a) {
-  __shared__ float red[2][4][64];
+__global__ __launch_bounds__(64 * TR_RG) void tr_bn_bwd_sums_kernel(BnActArgs a) {
+  __shared__ float red[2][TR_RG][64];
   const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rg = threadIdx.x >> 6, g = blockIdx.y;
   float s1 = 0.0f, s2 = 0.0f;
   if (c < a.N)
-    for (int b = rg; b < a.B; b += 4) {
+    for (int b = rg; b < a.B; b += TR_RG) {
       float xh;
       const float dy = tr_dy(a, ((long)g * a.B + b) * a.N + c, g, b, c, xh);
       s1 += dy;
@@ -220,8 +314,8 @@ __global__ __launch_bounds__(256) void tr_bn_bwd_sums_kernel(BnActArgs a) {
   __syncthreads();
   if (rg == 0 && c < a.N) {
     float* o = (float*)a.sums + (long)g * 2 * a.N;
-    o[c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-    o[a.N + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    o[c] = tr_rg_sum(red[0], cl);
+    o[a.N + c] = tr_rg_sum(red[1], cl);
   }
 }
 // dH = gamma * inv / B * (B*dy - sum dy - xhat * sum dy*xhat)
@@ -398,8 +492,11 @@ int tr_slabs(int R) {
 int gemm(hipStream_t st, const float* A, long sai, long sar, const float* Bm, long sbr, long sbj, float* C, int ldc, const float* bias,
          int M, int N, int R, int nslab = 1, long slab = 0) {
   TgArgs a{A, Bm, C, bias, M, N, R, sai, sar, sbr, sbj, ldc, 0, slab};
-  a.rper = ((R + nslab - 1) / nslab + 15) / 16 * 16;
-  hipLaunchKernelGGL(tg_gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, nslab), dim3(256), 0, st, a);
+  a.rper = ((R + nslab - 1) / nslab + 31) / 32 * 32;
+  if ((long)((N + 127) / 128) * ((M + 127) / 128) * nslab >= 192)
+    hipLaunchKernelGGL(tg_gemm128_kernel, dim3((N + 127) / 128, (M + 127) / 128, nslab), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(tg_gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, nslab), dim3(256), 0, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
@@ -461,11 +558,11 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
   };
   // ---------------- forward ----------------
   TR_RUN(gemm(st, x, 256, 1, pr + ST_TP_S_FC1_W, 1, 256, w.H1, 512, pr + ST_TP_S_FC1_B, GB, 512, 256));
-  hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(8, G), dim3(256), 0, st, w.H1, B, 512, w.mean1, w.var1);
+  hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(8, G), dim3(64 * TR_RG), 0, st, w.H1, B, 512, w.mean1, w.var1);
   BnActArgs f1 = bnargs(w.H1, w.mean1, w.var1, ST_TP_S_BN1_G, ST_TP_S_BN1_B, w.A1, 0, 512, GB, 0.0f, drop_p);
   hipLaunchKernelGGL(tr_bn_act_kernel, blocks((long)GB * 512), dim3(256), 0, st, f1);
   TR_RUN(gemm(st, w.A1, 512, 1, pr + ST_TP_S_FC2_W, 1, 512, w.H2, 512, pr + ST_TP_S_FC2_B, GB, 512, 512));
-  hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(8, G), dim3(256), 0, st, w.H2, B, 512, w.mean2, w.var2);
+  hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(8, G), dim3(64 * TR_RG), 0, st, w.H2, B, 512, w.mean2, w.var2);
   BnActArgs f2 = bnargs(w.H2, w.mean2, w.var2, ST_TP_S_BN2_G, ST_TP_S_BN2_B, w.A2, 1, 512, GB, 0.0f, drop_p);
   hipLaunchKernelGGL(tr_bn_act_kernel, blocks((long)GB * 512), dim3(256), 0, st, f2);
   TR_RUN(gemm(st, w.A2, 512, 1, pr + ST_TP_S_FC3_W, 1, 512, w.Z, 256, pr + ST_TP_S_FC3_B, GB, 256, 512));
@@ -473,7 +570,7 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
   BnActArgs fp{};
   if (!simplest) {
     TR_RUN(gemm(st, w.Z, 256, 1, pr + ST_TP_P_FC1_W, 1, 256, w.HP, 100, pr + ST_TP_P_FC1_B, B, 100, 256));
-    hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(2, 1), dim3(256), 0, st, w.HP, B, 100, w.pmean, w.pvar);
+    hipLaunchKernelGGL(tr_bn_stats_kernel, dim3(2, 1), dim3(64 * TR_RG), 0, st, w.HP, B, 100, w.pmean, w.pvar);
     fp = bnargs(w.HP, w.pmean, w.pvar, ST_TP_P_BN_G, ST_TP_P_BN_B, w.Q, 0, 100, B, 0.2f, 0.0f);
     hipLaunchKernelGGL(tr_bn_act_kernel, blocks((long)B * 100), dim3(256), 0, st, fp);
     TR_RUN(gemm(st, w.Q, 100, 1, pr + ST_TP_P_FC2_W, 1, 100, w.P, 256, pr + ST_TP_P_FC2_B, B, 256, 100));
@@ -495,7 +592,7 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
     TR_RUN(gemm(st, w.dP, 256, 1, pr + ST_TP_P_FC2_W, 100, 1, w.dQ, 100, nullptr, B, 100, 256));
     BnActArgs bp = fp;
     bp.dA = w.dQ; bp.sums = w.sums; bp.dH = w.dQ;
-    hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(2, 1), dim3(256), 0, st, bp);
+    hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(2, 1), dim3(64 * TR_RG), 0, st, bp);
     hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)B * 100), dim3(256), 0, st, bp);
     ST_HIP(hipMemcpyAsync(gr + ST_TP_P_BN_B, w.sums, 100 * 4, hipMemcpyDeviceToDevice, st));
     ST_HIP(hipMemcpyAsync(gr + ST_TP_P_BN_G, w.sums + 100, 100 * 4, hipMemcpyDeviceToDevice, st));
@@ -508,7 +605,7 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
   TR_RUN(gemm(st, w.dZ, 256, 1, pr + ST_TP_S_FC3_W, 512, 1, w.d512a, 512, nullptr, GbB, 512, 256));
   BnActArgs b2 = f2;
   b2.rows = GbB; b2.dA = w.d512a; b2.sums = w.sums; b2.dH = w.d512a;
-  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(256), 0, st, b2);
+  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(64 * TR_RG), 0, st, b2);
   hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)GbB * 512), dim3(256), 0, st, b2);
   // d beta / d gamma: sum over the calls of sums[g][0] / sums[g][1]
   hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums, Gb, 1024L, 512L, gr + ST_TP_S_BN2_B);
@@ -518,7 +615,7 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
   TR_RUN(gemm(st, w.d512a, 512, 1, pr + ST_TP_S_FC2_W, 512, 1, w.d512b, 512, nullptr, GbB, 512, 512));
   BnActArgs b1 = f1;
   b1.rows = GbB; b1.dA = w.d512b; b1.sums = w.sums; b1.dH = w.d512b;
-  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(256), 0, st, b1);
+  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(64 * TR_RG), 0, st, b1);
   hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)GbB * 512), dim3(256), 0, st, b1);
   hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums, Gb, 1024L, 512L, gr + ST_TP_S_BN1_B);
   hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums + 512, Gb, 1024L, 512L, gr + ST_TP_S_BN1_G);

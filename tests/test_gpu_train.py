@@ -117,7 +117,8 @@ def test_every_gradient_element_matches_the_oracle(dev, B, Kp, Kn, kw):
         # within rounding of zero can fall on the other side of the ReLU (a handful among 4.7 M units), which moves
         # single rows of a weight gradient by that unit's contribution: bound the bulk tightly and the outliers loosely.
         d = np.abs(gf[sl[k]] - ref)
-        assert (d <= 1.5e-3 * scale).mean() >= 0.999, (k, (d <= 1.5e-3 * scale).mean())
+        # (a flipped unit touches ONE element of a 512-element bias gradient: 0.2 % of that tensor, hence the floor of 2)
+        assert (d > 1.5e-3 * scale).sum() <= max(2, 0.001 * d.size), (k, int((d > 1.5e-3 * scale).sum()), d.size)
         assert d.max() <= 3e-2 * scale, (k, d.max(), scale)
         assert np.sqrt((d.astype(np.float64) ** 2).sum()) <= 2e-3 * np.sqrt((ref.astype(np.float64) ** 2).sum()), k
     s_sd, p_sd = tr.state_dicts()
