@@ -12,7 +12,7 @@
 
 #define SC_LD 516        // activation row stride in floats (512 + 4; = 4 mod 64 -> conflict-free b128)
 #define SC_ROWS 32
-#define SC_NW 8          // waves per workgroup: LDS allows one workgroup per CU, so 8 waves = 2 per SIMD
+#define SC_NW 8          // waves per workgroup; two workgroups per CU (79 KiB of LDS each) = 4 waves per SIMD
 #define SC_RPW (SC_ROWS / SC_NW)  // rows per wave in the row-wise phases
 #define SC_BUF (SC_ROWS * SC_LD)
 
@@ -23,7 +23,7 @@ enum { BWD_NONE = 0, BWD_RELU = 1, BWD_LRELU = 2 };
 //  forward  (FWD=true):  y = act(acc + bias[col]); sign bits of the pre-activation -> bits[row][chunk]
 //  backward (FWD=false): y = acc * act'(bits[row][chunk])
 template <int K, int N, bool FWD, int ACT>
-__device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float* __restrict__ Ys,
+__device__ __forceinline__ void tile_linear(const float* Xs, float* Ys,
                                             const float* __restrict__ W, const float* __restrict__ bias,
                                             uint32_t* __restrict__ bits, int bits_ld) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -42,9 +42,14 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float*
 #pragma unroll
     for (int j = 0; j < RW; ++j) ring[j] = wfrag(0, j);
   }
-  for (int ci = 0; ci < nch; ++ci) {
-    const int c = wave + SC_NW * ci;
-    f32x16 acc = {0};
+  // A wave owns at most two 32-column chunks (N <= 512, 8 waves): both are accumulated in registers, and the outputs
+  // are written only after EVERY wave has finished reading Xs, so Ys may be the same buffer as Xs.  One activation
+  // buffer instead of two brings the workgroup to 79 KiB of LDS: two workgroups share a CU and one's row-wise phases
+  // (scores, Adam, layer-start weight latency) run under the other's MFMAs.
+  static_assert(N / 32 <= 2 * SC_NW, "at most two chunks per wave");
+  auto compute = [&](int ci, f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const float* xr = Xs + l31 * SC_LD + 4 * half;
     for (int kg0 = 0; kg0 < KS; kg0 += RW) {
 #pragma unroll
@@ -57,6 +62,9 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float*
         for (int s = 0; s < 4; ++s) acc = mfma32(a[s], b[s], acc);
       }
     }
+  };
+  auto store = [&](int ci, const f32x16& acc) {
+    const int c = wave + SC_NW * ci;
     const int col = c * 32 + l31;
     const float bv = FWD ? bias[col] : 0.0f;
 #pragma unroll
@@ -82,7 +90,13 @@ __device__ __forceinline__ void tile_linear(const float* __restrict__ Xs, float*
       }
       Ys[row * SC_LD + col] = v;
     }
-  }
+  };
+  f32x16 acc0, acc1;
+  if (nch > 0) compute(0, acc0);
+  if (N / 32 > SC_NW && nch > 1) compute(1, acc1);
+  __syncthreads();
+  if (nch > 0) store(0, acc0);
+  if (N / 32 > SC_NW && nch > 1) store(1, acc1);
 }
 
 struct ScorerArgs {
@@ -110,11 +124,11 @@ struct ScorerArgs {
 };
 
 template <bool EDIT>
-__global__ __launch_bounds__(64 * SC_NW) void scorer_kernel(ScorerArgs a) {
+__global__ __launch_bounds__(64 * SC_NW, 4) void scorer_kernel(ScorerArgs a) {
   extern __shared__ __align__(16) float smem[];
-  float* bufA = smem;
-  float* bufB = smem + SC_BUF;
-  uint32_t* bits1 = (uint32_t*)(smem + 2 * SC_BUF);  // [32][16]
+  float* bufA = smem;  // the ONE activation buffer: every layer runs in place (tile_linear)
+  float* bufB = smem;
+  uint32_t* bits1 = (uint32_t*)(smem + SC_BUF);  // [32][16]
   uint32_t* bits2 = bits1 + 32 * 16;                 // [32][16]
   uint32_t* bitsq = bits2 + 32 * 16;                 // [32][4]
   float* cosv = (float*)(bitsq + 32 * 4);            // [32][32]
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(64 * SC_NW) void scorer_kernel(ScorerArgs a) {
   }
 }
 
-#define SC_LDS_BYTES ((2 * SC_BUF + 32 * 16 * 2 + 32 * 4 + 32 * 32 * 2) * 4)
+#define SC_LDS_BYTES ((SC_BUF + 32 * 16 * 2 + 32 * 4 + 32 * 32 * 2) * 4)
 
 static int check_scorer(const StScorerWeights* w) {
   ST_CHECK_ARG(w != nullptr, "scorer weights struct is NULL");
