@@ -189,6 +189,7 @@ int main(int argc, char** argv) {
     GemmArgs g = {};
     g.fmt = g_fmt;
     g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wqkv_p; g.bias = bias; g.N = 768; g.out = q; g.ldo = 768;
+    if (getenv("KBENCH_NOLN")) g.ln_a = g.ln_b = nullptr;  // ablation: no LayerNorm in the panel prologue
     const int sp = rp_splits(n, 768, 6);
     t = timeit([&] { launch_rp<EPI_BIAS>(g, n, sp, st); });
     printf("qkv(bias)  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * 768 / t / 1e12);
