@@ -39,6 +39,18 @@ def round_mantissa(x, bits):
     return r.astype(np.uint32).view(F32).reshape(np.shape(x))
 
 
+def to_e4m3(x):
+    """round to OCP fp8 e4m3fn (3 mantissa bits, exponent bias 7, subnormals down to 2^-9, saturating at 448): what
+    v_cvt_pk_fp8_f32 stores on gfx950"""
+    x = np.asarray(x, F32)
+    a = np.minimum(np.abs(x), F32(448.0))
+    e = np.floor(np.log2(np.maximum(a, F32(2.0 ** -20))))
+    e = np.maximum(e, -6.0)                      # below 2^-6 the spacing stays 2^-9 (subnormals)
+    q = np.exp2(e - 3.0)
+    r = np.round(a / q) * q                      # round half to even (np.round)
+    return (np.sign(x) * np.minimum(r, 448.0)).astype(F32)
+
+
 def make_linear(mode, sd):
     cache = {}
     if mode.startswith("kv:"):
@@ -54,6 +66,9 @@ def make_linear(mode, sd):
                     y = to_f16(y)
                 elif kind == "bf16":
                     y = to_bf16(y)
+                elif kind == "f16+e4m3":         # the packed cache: f16 value + fp8 residual scaled by 2^12 (3 bytes per element)
+                    h = to_f16(y)
+                    y = (h + to_e4m3((y - h).astype(F32) * F32(4096.0)) / F32(4096.0)).astype(F32)
                 elif kind.startswith("f16+m"):
                     h = to_f16(y)
                     y = (h + round_mantissa((y - h).astype(F32), int(kind[5:]))).astype(F32)
