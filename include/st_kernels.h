@@ -154,6 +154,8 @@ typedef struct StDecoderWeights {
   const float* pe;                     /* tgt_embed.1.pe [pe_rows,256]                          */
   const float *lnf_a, *lnf_b;          /* decoder.norm                                          */
   const float *gen_w, *gen_b;          /* generator.proj [V,256] PACKED (st_pack_weight), [V]   */
+  const float* gen_w_norm;             /* [V] ||generator.proj.weight[v]||_2, each rounded UP, or NULL: with it the screened
+                                          argmax bounds every column by its own norm instead of gen_w_maxnorm           */
   StDecLayer layer[ST_MAX_LAYERS];
 } StDecoderWeights;
 

@@ -18,7 +18,7 @@ ST_DEC_NO_SCREEN = 2
 ST_PROF_OFF, ST_PROF_GENERATOR, ST_PROF_HALF_LAYER = 0, 1, 2
 ST_GEMM_F32, ST_GEMM_F16X3 = 0, 1
 GEMM_FORMATS = {"f32": ST_GEMM_F32, "f16x3": ST_GEMM_F16X3}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -39,7 +39,7 @@ class StDecoderWeights(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
                 ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
                 ("gemm_format", C.c_int32), ("gen_w_maxnorm", C.c_float),
-                ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp), ("gen_w", fp), ("gen_b", fp),
+                ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp), ("gen_w", fp), ("gen_b", fp), ("gen_w_norm", fp),
                 ("layer", StDecLayer * ST_MAX_LAYERS)]
 
 

@@ -15,7 +15,7 @@ void st_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 4; }
+extern "C" int st_abi_version(void) { return 5; }
 
 // ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
 #include <vector>
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(const float4* __res
                                                      int32_t* __restrict__ ys, float* __restrict__ gap, int T, int pos,
                                                      int eos, int pad, int early, int last, int* __restrict__ idx_next,
                                                      int* __restrict__ n_next, const int* __restrict__ rows,
-                                                     float margin_c, int* __restrict__ amb_idx, int* __restrict__ n_amb) {
+                                                     float margin_c, int* __restrict__ amb_idx, int* __restrict__ n_amb,
+                                                     const float* __restrict__ wnorm, float cx_c) {
   __shared__ int app[FIN_THREADS / 64 + 1];
   const int i = blockIdx.x * FIN_THREADS + threadIdx.x;
   const bool valid = i < *n_dev;
@@ -288,7 +289,10 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(const float4* __res
   // rp_screen_kernel reports keys: logits with their low 8 mantissa bits replaced, i.e. each within 2^-15 of its
   // magnitude; the third term covers both values of any pair, whichever split they came from
   const float key_err = (1.01f / 16384.0f) * fmaxf(fabsf(t.m1), fabsf(t.m2));
-  const bool amb = valid && margin_c >= 0.0f && !(t.m1 - t.m2 > margin_c * norm + 1e-4f + key_err);
+  // wnorm: the partials are UPPER bounds u_v = s_v + cx ||W_v|| (cx = cx_c ||x||) of the exact logits: the winner's lower
+  // bound is u_1 - 2 cx ||W_i1||, and every other column's exact logit is below its own upper bound <= u_2
+  const float margin = wnorm ? (valid ? 2.0f * cx_c * norm * wnorm[t.i1] : 0.0f) : margin_c * norm;
+  const bool amb = valid && margin_c >= 0.0f && !(t.m1 - t.m2 > margin + 1e-4f + key_err);
   if (margin_c >= 0.0f) {  // uniform
     const int slot = block_append(n_amb, amb, app);
     if (amb) amb_idx[slot] = r;
@@ -541,10 +545,17 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_begin(&pp, 2.0 * 256.0 * (double)w->vocab, n_dev, n_bound, st));
     if (screen) {
       // pass 1: one-product logits for every live row; rows with a clear winner are finished
+      // per-column bound (gen_w_norm): the screening kernel books upper bounds, finish_kernel uses the winner's own norm
+      rp_ab_env();
+      const float cx_c = 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f);
+      static const bool ab_maxnorm = getenv("ST_AB_SCREEN_MAXNORM") != nullptr;  // A/B: the one-bound-for-all-columns margin
+      const float* wnorm = (rp_screen_shape16 && w->gen_w_norm && !ab_maxnorm) ? w->gen_w_norm : nullptr;
+      gg.wnorm = wnorm; gg.scale = cx_c;
       ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
+      gg.wnorm = nullptr;
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
-                         (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2);
+                         (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2, wnorm, cx_c);
       ST_LAUNCH_CHECK();
       // pass 2: the undecided rows again with the 3-product kernel (row gather through ws.amb; the grid covers
       // the worst case, workgroups beyond the ambiguous count exit at once)
@@ -553,13 +564,13 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, rsplits, st));
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, rsplits, idx, ws.cnt + 2,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
-                         (const int*)ws.amb, -1.0f, (int*)nullptr, (int*)nullptr);
+                         (const int*)ws.amb, -1.0f, (int*)nullptr, (int*)nullptr, (const float*)nullptr, 0.0f);
       ST_LAUNCH_CHECK();
     } else {
       ST_TRY(launch_rp<EPI_ARGMAX>(gg, n_bound, gsplits, st));
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, top2gap, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
-                         (const int*)nullptr, -1.0f, (int*)nullptr, (int*)nullptr);
+                         (const int*)nullptr, -1.0f, (int*)nullptr, (int*)nullptr, (const float*)nullptr, 0.0f);
       ST_LAUNCH_CHECK();
     }
     if (g_prof_on == ST_PROF_GENERATOR) ST_TRY(prof_end(&pp, st));

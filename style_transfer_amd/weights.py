@@ -91,7 +91,9 @@ class AEWeights(_Packed):
             s.d_model, s.n_heads, s.d_ff, s.n_layers, s.vocab, s.pe_rows = self.d_model, 4, self.d_ff, self.n_layers, self.vocab, pe.shape[0]
         self.dec.gemm_format = _lib.GEMM_FORMATS[gemm_format]
         # bound used by the screened argmax (st_kernels.h: gen_w_maxnorm), rounded up
-        self.dec.gen_w_maxnorm = float(sd["generator.proj.weight"].double().norm(dim=1).max()) * (1.0 + 1e-6)
+        gnorm = sd["generator.proj.weight"].double().norm(dim=1) * (1.0 + 1e-6)
+        self.dec.gen_w_maxnorm = float(gnorm.max())
+        self.dec.gen_w_norm = self.dev(torch.nextafter(gnorm.float(), torch.tensor(float("inf"))))   # per-column bound, rounded up
         self.dec.emb, self.dec.pe = self.emb_ptr, self.pe_ptr
         self.dec.lnf_a, self.dec.lnf_b = self.dev(sd["decoder.norm.a_2"]), self.dev(sd["decoder.norm.b_2"])
         self.dec.gen_w, self.dec.gen_b = self.packed(sd["generator.proj.weight"]), self.dev(sd["generator.proj.bias"])
