@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void rp_screen16_kernel(GemmArgs a) {
   __syncthreads();
 
   // With column norms (a.wnorm) the keys are UPPER BOUNDS of the exact logits, u = s + cx * ||W_v|| with
-  // cx = a.scale * ||x_row||: finish_kernel then needs only the winner's own norm for its margin (a vocabulary's largest
+  // cx = a.scale * ||x_row|| (added to the accumulators' initial value): finish_kernel then needs only the winner's own norm for its margin (a vocabulary's largest
   // row norm can be several times the typical one: amazon 2.87 against a median of 0.71).
   const bool ukeys = a.wnorm != nullptr && a.ln_a != nullptr;
   float cx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -681,12 +681,12 @@ __global__ __launch_bounds__(256, 2) void rp_screen16_kernel(GemmArgs a) {
   pn[1] = *(const f32x4*)(Ab + 16 * RS_LDA);
   // one block: 8 double k-steps into acc; meanwhile the previous block's accumulators (o; block number io) are booked,
   // two logits per half-step
-  auto block = [&](f32x4 (&acc)[2][4], f32x4 (&cn)[2], int i, const f32x4 (&o)[2][4], const f32x4 (&cno)[2], int io, bool do_book) {
+  auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_book) {
     const f32x4* Wb = wbase(i);
     const f32x4* Wn = wbase(i + 1);
     {
       const int col = ((b0 + wave + 4 * i) << 5) + 4 * g;
-      f32x4 bv[2];
+      f32x4 bv[2], cn[2];
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -695,11 +695,15 @@ __global__ __launch_bounds__(256, 2) void rp_screen16_kernel(GemmArgs a) {
           bv[ft][q] = cc < a.N ? (a.bias ? a.bias[cc] : 0.0f) : RS_PAD_LOGIT;
           cn[ft][q] = (ukeys && cc < a.N) ? a.wnorm[cc] : 0.0f;
         }
+      // the accumulators start from bias + cx * ||W_v||: the bound rides along in the initial value (an FMA where the
+      // plain form has a move), the bookkeeping stays at 3 operations per logit
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        acc[0][rt] = bv[0];
-        acc[1][rt] = bv[1];
-      }
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0][rt][q] = fmaf(cx[rt], cn[0][q], bv[0][q]);
+          acc[1][rt][q] = fmaf(cx[rt], cn[1][q], bv[1][q]);
+        }
     }
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
@@ -727,34 +731,34 @@ __global__ __launch_bounds__(256, 2) void rp_screen16_kernel(GemmArgs a) {
         if (do_book) {  // half-step u = 2d + hf books slot (ft, rt', q-pair): 16 half-steps x 2 logits = 32
           const int u = 2 * d + hf;
           const int ft = u & 1, rtb = (u >> 1) & 3, qp = u >> 3;  // registers 2 qp, 2 qp + 1
-          book(fmaf(cx[rtb], cno[ft][2 * qp], o[ft][rtb][2 * qp]), io, k1[ft][rtb][2 * qp], k2[ft][rtb][2 * qp]);
-          book(fmaf(cx[rtb], cno[ft][2 * qp + 1], o[ft][rtb][2 * qp + 1]), io, k1[ft][rtb][2 * qp + 1], k2[ft][rtb][2 * qp + 1]);
+          book(o[ft][rtb][2 * qp], io, k1[ft][rtb][2 * qp], k2[ft][rtb][2 * qp]);
+          book(o[ft][rtb][2 * qp + 1], io, k1[ft][rtb][2 * qp + 1], k2[ft][rtb][2 * qp + 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
-  auto book_all = [&](const f32x4 (&o)[2][4], const f32x4 (&cno)[2], int io) {
+  auto book_all = [&](const f32x4 (&o)[2][4], int io) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) book(fmaf(cx[rt], cno[ft][q], o[ft][rt][q]), io, k1[ft][rt][q], k2[ft][rt][q]);
+        for (int q = 0; q < 4; ++q) book(o[ft][rt][q], io, k1[ft][rt][q], k2[ft][rt][q]);
   };
-  f32x4 A[2][4], B[2][4], cnA[2], cnB[2];
+  f32x4 A[2][4], B[2][4];
   if (cnt > 0) {
-    block(A, cnA, 0, A, cnA, 0, false);
+    block(A, 0, A, 0, false);
     int i = 1;
     for (; i + 1 < cnt; i += 2) {
-      block(B, cnB, i, A, cnA, i - 1, true);
-      block(A, cnA, i + 1, B, cnB, i, true);
+      block(B, i, A, i - 1, true);
+      block(A, i + 1, B, i, true);
     }
     if (i < cnt) {  // an even number of blocks: one more into B, then book B
-      block(B, cnB, i, A, cnA, i - 1, true);
-      book_all(B, cnB, i);
+      block(B, i, A, i - 1, true);
+      book_all(B, i);
     } else {
-      book_all(A, cnA, cnt - 1);
+      book_all(A, cnt - 1);
     }
   }
   // keys -> (value, column, second): the 8 slots of a lane, then the 4 lanes (g) of a row, then the 4 waves through LDS
