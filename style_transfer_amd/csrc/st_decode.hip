@@ -286,9 +286,10 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(const float4* __res
     }
     r = rows ? rows[i] : i;
   }
-  // rp_screen_kernel reports keys: logits with their low 8 mantissa bits replaced, i.e. each within 2^-15 of its
-  // magnitude; the third term covers both values of any pair, whichever split they came from
-  const float key_err = (1.01f / 16384.0f) * fmaxf(fabsf(t.m1), fabsf(t.m2));
+  // the screening kernels report keys: logits with their low 9 (rp_screen16p_kernel; the other forms: 8) mantissa bits
+  // replaced, i.e. each within 2^-14 of its magnitude; the third term covers both values of any pair, whichever split
+  // they came from
+  const float key_err = (1.01f / 8192.0f) * fmaxf(fabsf(t.m1), fabsf(t.m2));
   // wnorm: the partials are UPPER bounds u_v = s_v + cx ||W_v|| (cx = cx_c ||x||) of the exact logits: the winner's lower
   // bound is u_1 - 2 cx ||W_i1||, and every other column's exact logit is below its own upper bound <= u_2
   const float margin = wnorm ? (valid ? 2.0f * cx_c * norm * wnorm[t.i1] : 0.0f) : margin_c * norm;
@@ -350,6 +351,7 @@ struct DecodeWs {
   int* amb;        // [B] live rows the screening pass could not decide
   int* cnt;        // [0],[1]: live counts (ping-pong), [2]: ambiguous rows of the current step
   float* slab;     // [d_ff/256][64][256] split-K partials of feed_forward.w_2 when one panel of rows is left
+  float* colpad;   // [2][32 ceil(vocab / 32)] padded generator bias and column norms (screening pass)
   size_t total;
 };
 #define ST_GEN_SPLITS 16        /* max column splits of the generator (partials per row) */
@@ -378,6 +380,7 @@ static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base)
   ws.amb = (int*)take((size_t)B * 4);
   ws.cnt = (int*)take(256);
   ws.slab = (float*)take((size_t)(w->d_ff / 256) * 64 * 256 * 4);
+  ws.colpad = (float*)take(rp_screen_colpad_floats(w->vocab) * 4);
   ws.total = off;
   return ws;
 }
@@ -451,6 +454,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   const bool screen_ok = w->gemm_format == ST_GEMM_F16X3 && top2gap == nullptr && w->gen_w_maxnorm > 0.0f &&
                          !(options & ST_DEC_NO_SCREEN);
   const float margin_c = 2.0f * 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f) * w->gen_w_maxnorm;
+  if (screen_ok) ST_TRY(launch_rp_screen_colpad(w->gen_b, w->gen_w_norm, w->vocab, ws.colpad, st));
   int n_bound = B;
   int cur = 0;
   int steps = 0;
@@ -550,9 +554,9 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       const float cx_c = 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f);
       static const bool ab_maxnorm = getenv("ST_AB_SCREEN_MAXNORM") != nullptr;  // A/B: the one-bound-for-all-columns margin
       const float* wnorm = (rp_screen_shape16 && w->gen_w_norm && !ab_maxnorm) ? w->gen_w_norm : nullptr;
-      gg.wnorm = wnorm; gg.scale = cx_c;
+      gg.wnorm = wnorm; gg.scale = cx_c; gg.colpad = ws.colpad;
       ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
-      gg.wnorm = nullptr;
+      gg.wnorm = nullptr; gg.colpad = nullptr;
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
                          (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2, wnorm, cx_c);

@@ -54,6 +54,7 @@ struct GemmArgs {
   int fmt;             // row-panel kernels: operand format of the packed W (ST_GEMM_F32 / ST_GEMM_F16X3)
   const int* xrows;    // row-panel kernels: optional gather, panel row r reads X[xrows[r]] (null = X[r])
   int* range_flag;     // f16x3: set to 1 when an activation leaves the f16 range (null = unchecked)
+  const float* colpad; // rp_screen16p_kernel: [2][32 ceil(N / 32)] bias (padding: RS_PAD_LOGIT) and column norms (padding: 0), see rp_screen_colpad_kernel
   const float* wnorm;  // rp_screen16_kernel: optional [N] 2-norms of the rows of W (rounded up): keys become UPPER BOUNDS
                        // s + scale * ||x|| * ||W_v|| of the exact logits (scale = slack * (2^-10 + 2^-16)), see finish_kernel
 };

@@ -46,6 +46,7 @@
 // ST_AB_SCREEN32 = the 32x32x16 screening pass.
 static int rp_lin_shape16 = 1;
 static int rp_screen_shape16 = 1;
+static int rp_screen_paired = 1;
 static int rp_tail_persistent = 1;
 static int rp_tail_shape16 = 1;
 static inline void rp_ab_env() {
@@ -56,6 +57,7 @@ static inline void rp_ab_env() {
   if (getenv("ST_AB_TAIL_ONE_PANEL")) rp_tail_persistent = 0;
   if (getenv("ST_AB_LIN32")) rp_lin_shape16 = 0;
   if (getenv("ST_AB_SCREEN32")) rp_screen_shape16 = 0;
+  if (getenv("ST_AB_SCREEN_UNPAIRED")) rp_screen_paired = 0;
 }
 
 
@@ -709,26 +711,35 @@ __global__ __launch_bounds__(256, 2) void rp_screen16_kernel(GemmArgs a) {
     for (int d = 0; d < 8; ++d) {
       const int sl = d & 3;
       const h8 w0 = as_h8(rw[sl][0]), w1 = as_h8(rw[sl][1]);
+#if !defined(ST_ABL_S_NOW)  /* kbench ablation: the W ring is never refilled */
       {
         const f32x4* Wx = d + 4 < 8 ? Wb + (d + 4) * 256 : Wn + (d + 4 - 8) * 256;
         rw[sl][0] = Wx[0];
         rw[sl][1] = Wx[16];
       }
+#endif
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const h8 p0 = as_h8(pn[0]), p1 = as_h8(pn[1]);
+#if !defined(ST_ABL_S_NOLDS)  /* kbench ablation: the panel fragments are never reloaded */
         {
           const int nd = hf ? ((d + 1) & 7) : d, nrt = hf ? 0 : 2;
           const float* q = Ab + nrt * 16 * RS_LDA + 16 * nd;
           pn[0] = *(const f32x4*)(q);
           pn[1] = *(const f32x4*)(q + 16 * RS_LDA);
         }
+#endif
         const int rt = 2 * hf;
         acc[0][rt] = mfma16x32h(w0, p0, acc[0][rt]);
         acc[1][rt] = mfma16x32h(w1, p0, acc[1][rt]);
         acc[0][rt + 1] = mfma16x32h(w0, p1, acc[0][rt + 1]);
         acc[1][rt + 1] = mfma16x32h(w1, p1, acc[1][rt + 1]);
-        if (do_book) {  // half-step u = 2d + hf books slot (ft, rt', q-pair): 16 half-steps x 2 logits = 32
+#if defined(ST_ABL_S_NOBOOK)  /* kbench ablation: one of the 32 logits of a block is booked */
+        if (do_book && d == 0 && hf == 0)
+#else
+        if (do_book)
+#endif
+        {  // half-step u = 2d + hf books slot (ft, rt', q-pair): 16 half-steps x 2 logits = 32
           const int u = 2 * d + hf;
           const int ft = u & 1, rtb = (u >> 1) & 3, qp = u >> 3;  // registers 2 qp, 2 qp + 1
           book(o[ft][rtb][2 * qp], io, k1[ft][rtb][2 * qp], k2[ft][rtb][2 * qp]);
@@ -801,6 +812,288 @@ __global__ __launch_bounds__(256, 2) void rp_screen16_kernel(GemmArgs a) {
     a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, rownorm[tid]);
   }
 }
+// LDS position (in dwords from the start of a panel row's hi or lo part) of the 8 halves that lane group g = lane >> 4 of a
+// 16x16x32 operand contracts in double step d (k = 32 d + 8 g .. + 7).  ds_read_b128 is served in four 16-lane groups,
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS): each holds all 16 values of
+// lane & 15 and TWO values of g, so with the natural order (position 16 d + 4 g, row stride = 4 mod 64) the g = 1 lanes
+// sit 4 banks beside the g = 0 lanes of the next row: a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT = 3.9 cycles per
+// instruction on the first 16x16x32 kernels).  Here g & 1 moves a fragment by 64 dwords = the bank modulus, and a group's
+// 16 lanes fall on 16 different 4-bank slots.
+__device__ __forceinline__ int rp16_frag_pos(int d, int g) { return 64 * (g & 1) + 8 * d + 4 * (g >> 1); }
+// the same for the writer that holds features 4 c4 .. 4 c4 + 3 of a row (2 dwords)
+__device__ __forceinline__ int rp16_quad_pos(int c4) { return rp16_frag_pos(c4 >> 3, (c4 >> 1) & 3) + 2 * (c4 & 1); }
+
+// bias and column norms of the screening pass, padded to whole 32-column blocks (out: [2][npad]): the kernel then loads
+// them 4 at a time and needs no per-column range test
+template <int UNUSED = 0>
+__global__ void rp_screen_colpad_kernel(const float* bias, const float* wnorm, int N, int npad, float* out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= npad) return;
+  out[c] = c < N ? (bias ? bias[c] : 0.0f) : RS_PAD_LOGIT;
+  out[npad + c] = (c < N && wnorm) ? wnorm[c] : 0.0f;
+}
+static inline size_t rp_screen_colpad_floats(int N) { return 2 * (size_t)((N + 31) / 32 * 32); }
+static int launch_rp_screen_colpad(const float* bias, const float* wnorm, int N, float* out, hipStream_t st) {
+  const int npad = (N + 31) / 32 * 32;
+  hipLaunchKernelGGL(rp_screen_colpad_kernel<0>, dim3((npad + 255) / 256), dim3(256), 0, st, bias, wnorm, N, npad, out);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+// ------------------------------------------------------------------------------------------------
+// rp_screen16_kernel with cheaper bookkeeping.  The compiled form of the kernel above spends FIVE VALU operations per
+// logit (v_and + v_or: a literal cannot sit in v_and_or_b32 next to a scalar; a v_max x,x,x that quiets the bit-cast
+// key before fmaxf; v_med3; v_max), and with the bookkeeping ablated the pass takes 40 % less time
+// (profiles/r02_screen_ablations.txt).  Here the two logits a lane holds for one (row, q) slot - feature tiles 0 and
+// 1 - share ONE (best, second) pair: key = (v & ~0x1ff) | (2 block + ft) in one v_and_or_b32 each, then
+//     second = max(second, med3(best, ka, kb)),  best = max3(best, ka, kb)
+// i.e. 2.5 operations per logit, 32 key registers instead of 64.  Keys sit within 2^-14 |v| of their logits
+// (finish_kernel's key_err covers two of them).  The W fragments are addressed as scalar base + 32-bit lane offset
+// (no 64-bit VALU address arithmetic per load), and the panel fragments of a half-step are requested before the
+// MFMAs of the half-step before it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rs_key(float v, unsigned keep, int code) {
+  float k;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(k) : "v"(v), "v"(keep), "s"(code));
+  return k;
+}
+__device__ __forceinline__ float rs_max(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float rs_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+#ifndef RS_PD
+#define RS_PD 3
+#endif
+template <bool UKEYS>  // UKEYS: a.wnorm and a.ln_a given, keys are upper bounds; a.colpad is required
+__global__ __launch_bounds__(256, 2) void rp_screen16p_kernel(GemmArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                  // [64][RS_LDA]
+  float* red = smem + 64 * RS_LDA;   // [4 waves][64 rows][4]
+  float* rownorm = red + 4 * 64 * 4; // [64]
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  {
+    // one wave per row, 16 rows each: global -> registers -> LayerNorm -> hi halves in LDS
+    f32x4 ga = {1, 1, 1, 1}, gb = {0, 0, 0, 0};
+    if (a.ln_a) {
+      ga = *(const f32x4*)(a.ln_a + lane * 4);
+      gb = *(const f32x4*)(a.ln_b + lane * 4);
+    }
+    f32x4 v[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = min(m0 + wave * 16 + rr, n - 1);
+      v[rr] = *(const f32x4*)(a.X + (size_t)(a.xrows ? a.xrows[r] : r) * 256 + lane * 4);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = wave * 16 + rr;
+      f32x4 y = v[rr];
+      float nrm = INFINITY;  // no LayerNorm, no norm: every row counts as ambiguous
+      if (a.ln_a) {
+        y = layernorm256r(y, ga, gb);
+        nrm = sqrtf(wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w));
+      }
+      if (lane == 0) rownorm[r] = nrm;
+      const float m = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+      bad |= !(m <= 65504.0f);
+      h4 hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi[j] = (_Float16)y[j];
+      *(h4*)(As + r * RS_LDA + rp16_quad_pos(lane)) = hi;
+    }
+    if (bad && a.range_flag) *a.range_flag = 1;
+  }
+  __syncthreads();
+
+  // with column norms the keys are upper bounds of the exact logits (see rp_screen16_kernel)
+  constexpr bool ukeys = UKEYS;
+  float cx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (ukeys) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) cx[rt] = a.scale * rownorm[16 * rt + r16];
+  }
+  float k1[4][4], k2[4][4];  // running (best, second) keys per (row tile, register), both feature tiles
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k1[rt][q] = k2[rt][q] = -INFINITY;
+  const int nblk = (a.N + 31) >> 5;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;  // column split blockIdx.y covers blocks [b0, b1)
+  const int b0 = blockIdx.y * per;
+  const int b1 = min(nblk, b0 + per);
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) / 4 : 0;  // this wave's blocks: b0 + wave, b0 + wave + 4, ...
+  const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);  // the lane's bytes inside a 4 KiB double step
+  const float* Ab = As + r16 * RS_LDA + rp16_frag_pos(0, g);
+  // W through a buffer descriptor: scalar block offset + the lane's 32-bit offset + immediate, no VALU address arithmetic.
+  // A block of the packed image is 32 KiB (8 double steps of [hi ft0 | hi ft1 | lo | lo] x 1 KiB).
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, nblk * 32768, 0x00020000);
+  auto wbase = [&](int i) -> int { return (b0 + wave + 4 * min(i, cnt - 1)) * 32768; };  // wave-uniform
+#if defined(ST_SCR_GLOBAL)
+  auto wfrag = [&](int p, int d, int ft) -> f32x4 { return *(const f32x4*)((const char*)a.W + (size_t)(unsigned)p + wl + d * 4096 + ft * 256); };
+#else
+  auto wfrag = [&](int p, int d, int ft) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + ft * 256, p + d * 4096, 0));
+  };
+#endif
+  unsigned keep = 0xfffffe00u;
+  asm volatile("" : "+v"(keep));  // one register for the whole loop (not a literal per use)
+  auto book2 = [&](float va, float vb, int io, float& b1, float& b2) {  // 5 VALU operations for two logits
+    const float ka = rs_key(va, keep, 2 * io), kb = rs_key(vb, keep, 2 * io + 1);
+    b2 = rs_max(b2, __builtin_amdgcn_fmed3f(b1, ka, kb));
+    b1 = rs_max3(b1, ka, kb);
+  };
+  f32x4 rw[4][2];  // W ring, four double steps deep: [slot][ft] (hi fragments only)
+  if (cnt > 0) {
+    const int W0 = wbase(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rw[j][0] = wfrag(W0, j, 0);
+      rw[j][1] = wfrag(W0, j, 1);
+    }
+  }
+  // panel fragments (hi), requested three half-steps ahead: half-step h = 2d + hf uses row tiles 2hf, 2hf + 1 of double
+  // step d out of pn[h & 3] (the LDS answers in more than one half-step's 4 MFMAs when two workgroups share it)
+  f32x4 pn[4][2];
+  auto pfrag = [&](int h, int j) -> f32x4 { return *(const f32x4*)(Ab + (2 * (h & 1) + j) * 16 * RS_LDA + 8 * ((h >> 1) & 7)); };
+#pragma unroll
+  for (int h = 0; h < RS_PD; ++h) {
+    pn[h][0] = pfrag(h, 0);
+    pn[h][1] = pfrag(h, 1);
+  }
+  // one block: 8 double k-steps into acc; meanwhile the previous block's accumulators (o; block number io) are booked,
+  // one (row tile, register) slot = two logits per half-step
+  auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_book) {
+    const int Wb = wbase(i);
+    const int Wn = wbase(i + 1);
+    {
+      const int col = ((b0 + wave + 4 * i) << 5) + 4 * g;
+      f32x4 bv[2], cn[2];  // from the padded copies: two or four 16-byte loads, no column-range selects
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        bv[ft] = *(const f32x4*)(a.colpad + col + 16 * ft);
+        cn[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (ukeys) cn[ft] = *(const f32x4*)(a.colpad + 32 * nblk + col + 16 * ft);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0][rt][q] = fmaf(cx[rt], cn[0][q], bv[0][q]);
+          acc[1][rt][q] = fmaf(cx[rt], cn[1][q], bv[1][q]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int sl = d & 3;
+      const h8 w0 = as_h8(rw[sl][0]), w1 = as_h8(rw[sl][1]);
+#if !defined(ST_ABL_S_NOW)  /* kbench ablation: the W ring is never refilled */
+      if (d + 4 < 8) {
+        rw[sl][0] = wfrag(Wb, d + 4, 0);
+        rw[sl][1] = wfrag(Wb, d + 4, 1);
+      } else {
+        rw[sl][0] = wfrag(Wn, d + 4 - 8, 0);
+        rw[sl][1] = wfrag(Wn, d + 4 - 8, 1);
+      }
+#endif
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int h = 2 * d + hf;
+        const h8 p0 = as_h8(pn[h & 3][0]), p1 = as_h8(pn[h & 3][1]);
+#if !defined(ST_ABL_S_NOLDS)  /* kbench ablation: the panel fragments are never reloaded */
+        pn[(h + RS_PD) & 3][0] = pfrag(h + RS_PD, 0);
+        pn[(h + RS_PD) & 3][1] = pfrag(h + RS_PD, 1);
+#endif
+#if !defined(ST_SCR_NOMIDBAR)
+        __builtin_amdgcn_sched_barrier(0);  // the requests go out before this half-step's MFMAs
+#endif
+        const int rt = 2 * hf;
+        acc[0][rt] = mfma16x32h(w0, p0, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(w1, p0, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(w0, p1, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(w1, p1, acc[1][rt + 1]);
+#if defined(ST_ABL_S_NOBOOK)  /* kbench ablation: one of the 16 slots of a block is booked */
+        if (do_book && d == 0 && hf == 0)
+#else
+        if (do_book)
+#endif
+        {  // half-step u = 2d + hf books slot (row tile u & 3, register u >> 2); row tiles 2, 3 were written last
+          const int u = 2 * d + hf, rtb = u & 3, q = u >> 2;
+          book2(o[0][rtb][q], o[1][rtb][q], io, k1[rtb][q], k2[rtb][q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto book_all = [&](const f32x4 (&o)[2][4], int io) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) book2(o[0][rt][q], o[1][rt][q], io, k1[rt][q], k2[rt][q]);
+  };
+  f32x4 A[2][4], B[2][4];
+  if (cnt > 0) {
+    block(A, 0, A, 0, false);
+    int i = 1;
+    for (; i + 1 < cnt; i += 2) {
+      block(B, i, A, i - 1, true);
+      block(A, i + 1, B, i, true);
+    }
+    if (i < cnt) {  // an even number of blocks: one more into B, then book B
+      block(B, i, A, i - 1, true);
+      book_all(B, i);
+    } else {
+      book_all(A, cnt - 1);
+    }
+  }
+  // keys -> (value, column, second): the 4 slots of a lane, then the 4 lanes (g) of a row, then the 4 waves through LDS
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Top2 u;
+      u.m1 = k1[rt][q];
+      const int code = __float_as_int(u.m1) & 0x1ff;
+      u.i1 = ((b0 + wave + 4 * (code >> 1)) << 5) + 16 * (code & 1) + 4 * g + q;
+      u.m2 = k2[rt][q];
+      t = top2_merge(t, u);
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      Top2 u;
+      u.m1 = __shfl_xor(t.m1, o, 64);
+      u.i1 = __shfl_xor(t.i1, o, 64);
+      u.m2 = __shfl_xor(t.m2, o, 64);
+      t = top2_merge(t, u);
+    }
+    if (g == 0) {
+      float* p = red + (wave * 64 + 16 * rt + r16) * 4;
+      p[0] = t.m1;
+      p[1] = __int_as_float(t.i1);
+      p[2] = t.m2;
+    }
+  }
+  __syncthreads();
+  if (tid < 64 && m0 + tid < n) {
+    Top2 t = {red[tid * 4 + 0], __float_as_int(red[tid * 4 + 1]), red[tid * 4 + 2]};
+    for (int w = 1; w < 4; ++w) {
+      Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
+      t = top2_merge(t, u);
+    }
+    a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, rownorm[tid]);
+  }
+}
 // grid (panels, column splits); needs ceil(N / 128) <= RS_MAX_BLOCKS (the block number must fit the 8 key bits)
 static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   ST_ENSURE_LDS((rp_screen_kernel<0>), RS_LDS);
@@ -810,7 +1103,14 @@ static int launch_rp_screen_pipelined(const GemmArgs& a, int n_bound, int splits
     return ST_EINVAL;
   }
   rp_ab_env();
-  if (rp_screen_shape16) {
+  if (rp_screen_shape16 && rp_screen_paired && a.colpad) {
+    ST_ENSURE_LDS((rp_screen16p_kernel<true>), RS_LDS);
+    ST_ENSURE_LDS((rp_screen16p_kernel<false>), RS_LDS);
+    if (a.wnorm && a.ln_a)
+      hipLaunchKernelGGL((rp_screen16p_kernel<true>), dim3((n_bound + 63) / 64, splits), dim3(256), RS_LDS, st, a);
+    else
+      hipLaunchKernelGGL((rp_screen16p_kernel<false>), dim3((n_bound + 63) / 64, splits), dim3(256), RS_LDS, st, a);
+  } else if (rp_screen_shape16) {
     ST_ENSURE_LDS((rp_screen16_kernel<0>), RS_LDS);
     hipLaunchKernelGGL((rp_screen16_kernel<0>), dim3((n_bound + 63) / 64, splits), dim3(256), RS_LDS, st, a);
   } else {
