@@ -22,6 +22,7 @@
 
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 // streaming outputs (written once, read by a later kernel): nontemporal stores keep them from evicting
 // the L2-resident weights
@@ -89,6 +90,18 @@ __device__ __forceinline__ void panel_store4_nb(float* row, int c4, f32x4 v, int
   _Float16* ph = (_Float16*)row;
   *(h4*)(ph + c4 * 4) = hi;
   *(h4*)(ph + 256 + c4 * 4) = lo;
+}
+
+// panel_store4_nb for the K-permuted rows of the 16x16x32 kernels (rp16_quad_pos, defined with the screening kernels below)
+__device__ __forceinline__ int rp16_frag_pos(int d, int g);
+__device__ __forceinline__ int rp16_quad_pos(int c4);
+__device__ __forceinline__ void panel_store4_nb16(float* row, int c4, f32x4 v, int& bad) {
+  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  bad |= !(m <= 65504.0f);
+  h4 hi, lo;
+  split_f16(v, hi, lo);
+  *(h4*)(row + rp16_quad_pos(c4)) = hi;
+  *(h4*)(row + 128 + rp16_quad_pos(c4)) = lo;
 }
 
 // D(16 x 16) += A(16 x 32) . B(32 x 16) on f16: lane l holds A[row l & 15][k = 8 (l >> 4) .. +7], B[k = same][col l & 15];
@@ -1283,6 +1296,9 @@ __global__ __launch_bounds__(256, 2) void rp_lin_kernel(GemmArgs a) {
 // epilogue of 8 16-byte stores per lane and block (4 consecutive features of one row) instead of 32 dwords.
 // Needs N % 32 == 0 and 16-byte aligned output rows (ldo % 4, kv_stride % 4).
 // ------------------------------------------------------------------------------------------------
+#ifndef RP_LIN_RING
+#define RP_LIN_RING 2  /* 2, 4 or 8; 4 measured the same (313.6 against 317.9 us at 229 k rows) for 28 more registers */
+#endif
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void rp_lin16_kernel(GemmArgs a) {
   static_assert(EPI == EPI_BIAS || EPI == EPI_QKV, "rp_lin16_kernel: BIAS or QKV");
@@ -1308,14 +1324,14 @@ __global__ __launch_bounds__(256, 2) void rp_lin16_kernel(GemmArgs a) {
 #pragma unroll 4
     for (int rr = 0; rr < 16; ++rr) {
       float* row = As + (wave * 16 + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
-      panel_store4_nb(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
+      panel_store4_nb16(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int f = tid + i * 256;
       const int r = f >> 6, c4 = f & 63;
-      panel_store4_nb(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4), bad);
+      panel_store4_nb16(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4), bad);
     }
   }
   int* slot = (int*)(smem + 64 * ST_LDA);  // QKV: the K/V cache slot (job) of each panel row
@@ -1327,115 +1343,136 @@ __global__ __launch_bounds__(256, 2) void rp_lin16_kernel(GemmArgs a) {
   const int b0 = blockIdx.y * per;
   const int b1 = min(nblk, b0 + per);
   const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) / 4 : 0;  // this wave's blocks: b0 + wave, b0 + wave + 4, ...
-  const f32x4* Wl = (const f32x4*)a.W + (g >> 1) * 128 + 32 * (g & 1) + r16;
-  const float* Ab = As + r16 * ST_LDA + 4 * g;
-  auto wbase = [&](int i) -> const f32x4* { return Wl + (size_t)(b0 + wave + 4 * min(i, cnt - 1)) * 16 * 128; };
-  auto wfetch = [&](const f32x4* Wb, int d, f32x4 (&dst)[4]) {
-    dst[0] = Wb[d * 256];
-    dst[1] = Wb[d * 256 + 64];
-    dst[2] = Wb[d * 256 + 16];
-    dst[3] = Wb[d * 256 + 80];
+  // W through a buffer descriptor: scalar block offset + the lane's 32-bit offset + immediate (no VALU address
+  // arithmetic); a block of the packed image is 32 KiB = 8 double steps of [hi ft0 | hi ft1 | .. | lo ft0 | lo ft1] KiB
+  const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, nblk * 32768, 0x00020000);
+  const float* Ab = As + r16 * ST_LDA + rp16_frag_pos(0, g);  // K-permuted panel rows: conflict-free ds_read_b128
+  auto wbase = [&](int i) -> int { return (b0 + wave + 4 * min(i, cnt - 1)) * 32768; };  // wave-uniform
+  auto wfetch = [&](int p, int d, f32x4 (&dst)[4]) {
+    dst[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl, p + d * 4096, 0));
+    dst[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1024, p + d * 4096, 0));
+    dst[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 256, p + d * 4096, 0));
+    dst[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1280, p + d * 4096, 0));
   };
-  auto put = [&](const f32x4& v, int i, int ft, int rt) {
-    const int blk = b0 + wave + 4 * i;  // wave-uniform: a 32-column block lies entirely in q, k or v
-    const int col = (blk << 5) + 16 * ft + 4 * g;
+  // where the lane's four rows (one per row tile) go, computed once: element offset of (row, feature 4 g) in the plain
+  // output / q, and of the row's K/V cache slot
+  size_t orow[4], kvrow[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
     const int rl = 16 * rt + r16;
-    if (m0 + rl >= n) return;
+    orow[rt] = (size_t)min(m0 + rl, n - 1) * (EPI == EPI_BIAS ? a.ldo : 256) + 4 * g;
+    kvrow[rt] = EPI == EPI_QKV ? (size_t)((long)slot[rl] * a.kv_stride) + 4 * g : 0;
+  }
+  // FULL: every row of the panel exists (all panels but the last): the stores need no row test
+  auto run = [&](auto FULL) {
+    auto put = [&](const f32x4& v, int i, int ft, int rt) {
+      const int blk = b0 + wave + 4 * i;  // wave-uniform: a 32-column block lies entirely in q, k or v
+      const int colu = (blk << 5) + 16 * ft;  // uniform part of the column
+      if (!decltype(FULL)::value && m0 + 16 * rt + r16 >= n) return;
 #if defined(ST_ABL_NOSTORE)  /* kbench ablation: keep the value live, never store */
-    if (v.x != 1.2345e-30f) return;
+      if (v.x != 1.2345e-30f) return;
 #endif
-    if (EPI == EPI_BIAS) {
-      ST_STORE4((f32x4*)&a.out[(size_t)(m0 + rl) * a.ldo + col], v);
-    } else if (blk < 8) {
-      ST_STORE4((f32x4*)&a.q[(size_t)(m0 + rl) * 256 + col], v);
-    } else {
-      float* base = (blk < 16) ? a.kbase : a.vbase;
-      ST_STORE4((f32x4*)&base[(long)slot[rl] * a.kv_stride + (col & 255)], v);
-    }
-  };
-  f32x4 rw[2][4];
-  if (cnt > 0) {
-    wfetch(wbase(0), 0, rw[0]);
-    wfetch(wbase(0), 1, rw[1]);
-  }
-  f32x4 pn[4];
-  pn[0] = *(const f32x4*)(Ab);
-  pn[1] = *(const f32x4*)(Ab + 128);
-  pn[2] = *(const f32x4*)(Ab + 16 * ST_LDA);
-  pn[3] = *(const f32x4*)(Ab + 16 * ST_LDA + 128);
-  // one block: 8 double k-steps into acc; meanwhile the previous block's accumulators (o; block number io) are stored,
-  // one 16-byte store per double step
-  auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_put) {
-    const f32x4* Wb = wbase(i);
-    const f32x4* Wn = wbase(i + 1);
-    {
-      const int col = ((b0 + wave + 4 * i) << 5) + 4 * g;
-      const f32x4 z = {0, 0, 0, 0};
-      const f32x4 bv0 = a.bias ? *(const f32x4*)(a.bias + col) : z, bv1 = a.bias ? *(const f32x4*)(a.bias + col + 16) : z;
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        acc[0][rt] = bv0;
-        acc[1][rt] = bv1;
+      if (EPI == EPI_BIAS) {
+        ST_STORE4((f32x4*)(a.out + colu + orow[rt]), v);
+      } else if (blk < 8) {
+        ST_STORE4((f32x4*)(a.q + colu + orow[rt]), v);
+      } else {
+        float* base = (blk < 16) ? a.kbase : a.vbase;
+        ST_STORE4((f32x4*)(base + (colu & 255) + kvrow[rt]), v);
       }
+    };
+    // W ring, RP_LIN_RING double steps deep.  Loads and stores share one in-order counter (vmcnt): the wait for a W
+    // fragment also waits for every output store issued before that load, so the ring depth is the time a store gets to
+    // be acknowledged before it stalls the MFMAs (2 steps = 0.5 us: the kernel then runs at memory time PLUS MFMA time).
+    f32x4 rw[RP_LIN_RING][4];
+    if (cnt > 0) {
+#pragma unroll
+      for (int j = 0; j < RP_LIN_RING; ++j) wfetch(wbase(0), j, rw[j]);
     }
+    f32x4 pn[4];
+    pn[0] = *(const f32x4*)(Ab);
+    pn[1] = *(const f32x4*)(Ab + 128);
+    pn[2] = *(const f32x4*)(Ab + 16 * ST_LDA);
+    pn[3] = *(const f32x4*)(Ab + 16 * ST_LDA + 128);
+    // one block: 8 double k-steps into acc; meanwhile the previous block's accumulators (o; block number io) are stored,
+    // one 16-byte store per double step
+    auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_put) {
+      const int Wb = wbase(i);
+      const int Wn = wbase(i + 1);
+      {
+        const int col = ((b0 + wave + 4 * i) << 5) + 4 * g;
+        const f32x4 z = {0, 0, 0, 0};
+        const f32x4 bv0 = a.bias ? *(const f32x4*)(a.bias + col) : z, bv1 = a.bias ? *(const f32x4*)(a.bias + col + 16) : z;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      const int sl = d & 1;
-      const h8 wh0 = as_h8(rw[sl][0]), wl0 = as_h8(rw[sl][1]), wh1 = as_h8(rw[sl][2]), wl1 = as_h8(rw[sl][3]);
-      if (d + 2 < 8)
-        wfetch(Wb, d + 2, rw[sl]);
-      else
-        wfetch(Wn, d + 2 - 8, rw[sl]);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
-        {
-          const int nd = hf ? ((d + 1) & 7) : d, nrt = hf ? 0 : 2;
-          const float* q = Ab + nrt * 16 * ST_LDA + 16 * nd;
-          pn[0] = *(const f32x4*)(q);
-          pn[1] = *(const f32x4*)(q + 128);
-          pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
-          pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+        for (int rt = 0; rt < 4; ++rt) {
+          acc[0][rt] = bv0;
+          acc[1][rt] = bv1;
         }
-        const int rt = 2 * hf;
-        acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
-        acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
-        acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
-        acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
-        acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
-        acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
-        acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
-        acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
-        acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
-        acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
-        acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
-        acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
-        if (do_put && hf == 1) put(o[d & 1][d >> 1], io, d & 1, d >> 1);
-        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const int sl = d % RP_LIN_RING;
+        const h8 wh0 = as_h8(rw[sl][0]), wl0 = as_h8(rw[sl][1]), wh1 = as_h8(rw[sl][2]), wl1 = as_h8(rw[sl][3]);
+        if (d + RP_LIN_RING < 8)
+          wfetch(Wb, d + RP_LIN_RING, rw[sl]);
+        else
+          wfetch(Wn, d + RP_LIN_RING - 8, rw[sl]);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+          {
+            const int nd = hf ? ((d + 1) & 7) : d, nrt = hf ? 0 : 2;
+            const float* q = Ab + nrt * 16 * ST_LDA + 8 * nd;
+            pn[0] = *(const f32x4*)(q);
+            pn[1] = *(const f32x4*)(q + 128);
+            pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+            pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+          }
+          const int rt = 2 * hf;
+          acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
+          acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
+          acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
+          acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
+          acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
+          acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
+          acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
+          acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
+          acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
+          acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
+          acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
+          acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
+          if (do_put && hf == 1) put(o[d & 1][d >> 1], io, d & 1, d >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    f32x4 A[2][4], B[2][4];
+    if (cnt > 0) {
+      block(A, 0, A, 0, false);
+      int i = 1;
+      for (; i + 1 < cnt; i += 2) {
+        block(B, i, A, i - 1, true);
+        block(A, i + 1, B, i, true);
+      }
+      if (i < cnt) {
+        block(B, i, A, i - 1, true);
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) put(B[ft][rt], i, ft, rt);
+      } else {
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) put(A[ft][rt], cnt - 1, ft, rt);
       }
     }
   };
-  f32x4 A[2][4], B[2][4];
-  if (cnt > 0) {
-    block(A, 0, A, 0, false);
-    int i = 1;
-    for (; i + 1 < cnt; i += 2) {
-      block(B, i, A, i - 1, true);
-      block(A, i + 1, B, i, true);
-    }
-    if (i < cnt) {
-      block(B, i, A, i - 1, true);
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) put(B[ft][rt], i, ft, rt);
-    } else {
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) put(A[ft][rt], cnt - 1, ft, rt);
-    }
-  }
+  if (m0 + 64 <= n)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
   if (bad && a.range_flag) *a.range_flag = 1;
 }
 template <int EPI>

@@ -118,6 +118,27 @@ __global__ __launch_bounds__(512) void mfma_valu_kernel(float* out, const float*
   if (s == 1.2345f) out[threadIdx.x] = s;
 }
 
+// Memory floor of the QKV projection: read a [n,256] f32 matrix once, write a [n,768] one (nontemporal 16-byte stores),
+// no arithmetic.  One workgroup per 64-row panel like the real kernels.
+__global__ __launch_bounds__(256) void qkv_floor_kernel(const float* x, float* out, int n) {
+  const int m0 = blockIdx.x * 64, tid = threadIdx.x;
+  f32x4 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int f = tid + i * 256, r = f >> 6, c4 = f & 63;
+    v[i] = *(const f32x4*)(x + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int f = tid + i * 256, r = f >> 6, c4 = f & 63;
+    if (m0 + r >= n) continue;
+    float* o = out + (size_t)(m0 + r) * 768 + c4 * 4;
+    __builtin_nontemporal_store(v[i], (f32x4*)o);
+    __builtin_nontemporal_store(v[i], (f32x4*)(o + 256));
+    __builtin_nontemporal_store(v[i], (f32x4*)(o + 512));
+  }
+}
+
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 65536;
   g_fmt = argc > 3 ? atoi(argv[3]) : ST_GEMM_F32;  // kbench <rows> <generator splits, 0 = auto> <format>
@@ -178,6 +199,10 @@ int main(int argc, char** argv) {
         printf("16x16x32 MFMA loop + %d v_max3_f32 per MFMA, %d waves per SIMD: %8.1f us  %7.1f TF  (x %.3f)\n", j, wg_threads / 256,
                tv[j] * 1e6, fl / tv[j] / 1e12, tv[j] / tv[0]);
     }
+  }
+  if (want('m')) {  // memory floor of the QKV projection
+    t = timeit([&] { hipLaunchKernelGGL(qkv_floor_kernel, dim3((n + 63) / 64), dim3(256), 0, st, x, q, n); }, 10);
+    printf("qkv memory floor (read [n,256], write [n,768], no arithmetic) n=%d: %8.1f us  %.2f TB/s\n", n, t * 1e6, (double)n * 4096 / t / 1e12);
   }
   if (want('g')) {  // generator
     GemmArgs g = {};
