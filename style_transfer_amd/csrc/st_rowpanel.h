@@ -880,7 +880,10 @@ __device__ __forceinline__ float rs_max3(float a, float b, float c) {
   return d;
 }
 #ifndef RS_PD
-#define RS_PD 3
+#define RS_PD 1
+#endif
+#ifndef RS_WRING
+#define RS_WRING 4  /* 4 or 8 double steps */
 #endif
 template <bool UKEYS>  // UKEYS: a.wnorm and a.ln_a given, keys are upper bounds; a.colpad is required
 __global__ __launch_bounds__(256, 2) void rp_screen16p_kernel(GemmArgs a) {
@@ -966,11 +969,11 @@ __global__ __launch_bounds__(256, 2) void rp_screen16p_kernel(GemmArgs a) {
     b2 = rs_max(b2, __builtin_amdgcn_fmed3f(b1, ka, kb));
     b1 = rs_max3(b1, ka, kb);
   };
-  f32x4 rw[4][2];  // W ring, four double steps deep: [slot][ft] (hi fragments only)
+  f32x4 rw[RS_WRING][2];  // W ring, RS_WRING double steps deep: [slot][ft] (hi fragments only)
   if (cnt > 0) {
     const int W0 = wbase(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RS_WRING; ++j) {
       rw[j][0] = wfrag(W0, j, 0);
       rw[j][1] = wfrag(W0, j, 1);
     }
@@ -1008,15 +1011,15 @@ __global__ __launch_bounds__(256, 2) void rp_screen16p_kernel(GemmArgs a) {
     }
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      const int sl = d & 3;
+      const int sl = d % RS_WRING;
       const h8 w0 = as_h8(rw[sl][0]), w1 = as_h8(rw[sl][1]);
 #if !defined(ST_ABL_S_NOW)  /* kbench ablation: the W ring is never refilled */
-      if (d + 4 < 8) {
-        rw[sl][0] = wfrag(Wb, d + 4, 0);
-        rw[sl][1] = wfrag(Wb, d + 4, 1);
+      if (d + RS_WRING < 8) {
+        rw[sl][0] = wfrag(Wb, d + RS_WRING, 0);
+        rw[sl][1] = wfrag(Wb, d + RS_WRING, 1);
       } else {
-        rw[sl][0] = wfrag(Wn, d + 4 - 8, 0);
-        rw[sl][1] = wfrag(Wn, d + 4 - 8, 1);
+        rw[sl][0] = wfrag(Wn, d + RS_WRING - 8, 0);
+        rw[sl][1] = wfrag(Wn, d + RS_WRING - 8, 1);
       }
 #endif
 #pragma unroll
