@@ -454,7 +454,8 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   const bool screen_ok = w->gemm_format == ST_GEMM_F16X3 && top2gap == nullptr && w->gen_w_maxnorm > 0.0f &&
                          !(options & ST_DEC_NO_SCREEN);
   const float margin_c = 2.0f * 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f) * w->gen_w_maxnorm;
-  if (screen_ok) ST_TRY(launch_rp_screen_colpad(w->gen_b, w->gen_w_norm, w->vocab, ws.colpad, st));
+  // padded generator bias / column norms: the 16x16x32 generator kernels (screening pass, exact argmax) load them 4 at a time
+  if (w->gemm_format == ST_GEMM_F16X3) ST_TRY(launch_rp_screen_colpad(w->gen_b, w->gen_w_norm, w->vocab, ws.colpad, st));
   int n_bound = B;
   int cur = 0;
   int steps = 0;
@@ -539,6 +540,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     gg.fmt = w->gemm_format; gg.range_flag = ws.cnt + 3;
     gg.X = ws.x; gg.n_dev = n_dev; gg.n_host = n_bound; gg.ln_a = w->lnf_a; gg.ln_b = w->lnf_b;
     gg.W = w->gen_w; gg.bias = w->gen_b; gg.N = w->vocab; gg.partial = ws.partial;
+    gg.colpad = w->gemm_format == ST_GEMM_F16X3 ? ws.colpad : nullptr;
     // partial buffer: B * ST_GEN_SPLITS + 64 * ST_GEN_SPLITS_SMALL entries
     const long room = ((long)B * ST_GEN_SPLITS + 64L * ST_GEN_SPLITS_SMALL) / n_bound;
     const int gsplits = rp_splits(n_bound, w->vocab, (int)(room < ST_GEN_SPLITS_SMALL ? (room < ST_GEN_SPLITS ? ST_GEN_SPLITS : room) : ST_GEN_SPLITS_SMALL));
@@ -554,9 +556,9 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       const float cx_c = 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f);
       static const bool ab_maxnorm = getenv("ST_AB_SCREEN_MAXNORM") != nullptr;  // A/B: the one-bound-for-all-columns margin
       const float* wnorm = (rp_screen_shape16 && w->gen_w_norm && !ab_maxnorm) ? w->gen_w_norm : nullptr;
-      gg.wnorm = wnorm; gg.scale = cx_c; gg.colpad = ws.colpad;
+      gg.wnorm = wnorm; gg.scale = cx_c;
       ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
-      gg.wnorm = nullptr; gg.colpad = nullptr;
+      gg.wnorm = nullptr;
       hipLaunchKernelGGL(finish_kernel, dim3((n_bound + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, st, ws.partial, gsplits, idx, n_dev,
                          out_ids, (float*)nullptr, T, pos, eos, pad, early, last, ws.idx[cur ^ 1], ws.cnt + (cur ^ 1),
                          (const int*)nullptr, margin_c, ws.amb, ws.cnt + 2, wnorm, cx_c);

@@ -48,6 +48,7 @@
 static int rp_lin_shape16 = 1;
 static int rp_screen_shape16 = 1;
 static int rp_screen_paired = 1;
+static int rp_argmax_shape16 = 1;
 static int rp_tail_persistent = 1;
 static int rp_tail_shape16 = 1;
 static inline void rp_ab_env() {
@@ -59,6 +60,7 @@ static inline void rp_ab_env() {
   if (getenv("ST_AB_LIN32")) rp_lin_shape16 = 0;
   if (getenv("ST_AB_SCREEN32")) rp_screen_shape16 = 0;
   if (getenv("ST_AB_SCREEN_UNPAIRED")) rp_screen_paired = 0;
+  if (getenv("ST_AB_ARGMAX32")) rp_argmax_shape16 = 0;
 }
 
 
@@ -1478,6 +1480,216 @@ __global__ __launch_bounds__(256, 2) void rp_lin16_kernel(GemmArgs a) {
     run(std::false_type{});
   if (bad && a.range_flag) *a.range_flag = 1;
 }
+// ------------------------------------------------------------------------------------------------
+// Exact argmax (three products per term) on 16x16x32 tiles: the redo pass of the screened argmax and the generator of
+// small or unscreened batches in the f16x3 format.  rp_lin16_kernel's loop (W as the A operand, K-permuted panel rows,
+// buffer-descriptor W loads) with rp_screen16p_kernel's slot structure: the two logits a lane holds for one (row tile,
+// register) slot - feature tiles 0 and 1 - share one exact (best, code, second) triple, code = 2 block + ft; columns
+// reach a slot in increasing order and `>` is strict, so exact ties keep the lowest column.  Bookkeeping of block i - 1
+// (4 operations per logit) sits inside the MFMAs of block i; the final merge is local over a lane's 4 slots plus two
+// lane exchanges per row tile (rp_gemm_kernel<EPI_ARGMAX>: five exchanges for each of 32 slots, which with 16 column
+// splits cost as much as the workgroup's MFMAs).  Needs a.colpad (padded bias: columns >= N never win).
+// ------------------------------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256, 2) void rp_argmax16_kernel(GemmArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                 // [64][ST_LDA]
+  float* red = smem + 64 * ST_LDA;  // [4 waves][64 rows][4]
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  auto xrow = [&](int r) -> int { return a.xrows ? a.xrows[r] : r; };  // optional row gather (redo pass)
+  int bad = 0;
+  if (a.ln_a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 6, c4 = f & 63;
+      *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)xrow(min(m0 + r, n - 1)) * 256 + c4 * 4);
+    }
+    __syncthreads();
+    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      float* row = As + (wave * 16 + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
+      panel_store4_nb16(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 6, c4 = f & 63;
+      panel_store4_nb16(As + r * ST_LDA, c4, *(const f32x4*)(a.X + (size_t)xrow(min(m0 + r, n - 1)) * 256 + c4 * 4), bad);
+    }
+  }
+  __syncthreads();
+
+  const int nblk = (a.N + 31) >> 5;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;  // column split blockIdx.y covers blocks [b0, b1)
+  const int b0 = blockIdx.y * per;
+  const int b1 = min(nblk, b0 + per);
+  const int cnt = (b1 - b0 > wave) ? (b1 - b0 - wave + 3) / 4 : 0;  // this wave's blocks: b0 + wave, b0 + wave + 4, ...
+  const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, nblk * 32768, 0x00020000);
+  const float* Ab = As + r16 * ST_LDA + rp16_frag_pos(0, g);
+  auto wbase = [&](int i) -> int { return (b0 + wave + 4 * min(i, cnt - 1)) * 32768; };  // wave-uniform
+  auto wfetch = [&](int p, int d, f32x4 (&dst)[4]) {
+    dst[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl, p + d * 4096, 0));
+    dst[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1024, p + d * 4096, 0));
+    dst[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 256, p + d * 4096, 0));
+    dst[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1280, p + d * 4096, 0));
+  };
+  float m1[4][4], m2[4][4];  // exact (best, second) per (row tile, register) slot, both feature tiles
+  int bc[4][4];              // code of the best: 2 block + feature tile
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      m1[rt][q] = m2[rt][q] = -INFINITY;
+      bc[rt][q] = 0;
+    }
+  auto book = [&](float v, int code, float& b1, int& c1, float& b2) {  // 4 VALU operations
+    c1 = v > b1 ? code : c1;
+    b2 = __builtin_amdgcn_fmed3f(b1, v, b2);
+    b1 = rs_max(b1, v);
+  };
+  f32x4 rw[2][4];
+  if (cnt > 0) {
+    wfetch(wbase(0), 0, rw[0]);
+    wfetch(wbase(0), 1, rw[1]);
+  }
+  f32x4 pn[4];
+  pn[0] = *(const f32x4*)(Ab);
+  pn[1] = *(const f32x4*)(Ab + 128);
+  pn[2] = *(const f32x4*)(Ab + 16 * ST_LDA);
+  pn[3] = *(const f32x4*)(Ab + 16 * ST_LDA + 128);
+  auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_book) {
+    const int Wb = wbase(i);
+    const int Wn = wbase(i + 1);
+    {
+      const int col = ((b0 + wave + 4 * i) << 5) + 4 * g;
+      const f32x4 bv0 = *(const f32x4*)(a.colpad + col), bv1 = *(const f32x4*)(a.colpad + col + 16);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[0][rt] = bv0;
+        acc[1][rt] = bv1;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int sl = d & 1;
+      const h8 wh0 = as_h8(rw[sl][0]), wl0 = as_h8(rw[sl][1]), wh1 = as_h8(rw[sl][2]), wl1 = as_h8(rw[sl][3]);
+      if (d + 2 < 8)
+        wfetch(Wb, d + 2, rw[sl]);
+      else
+        wfetch(Wn, d + 2 - 8, rw[sl]);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+        {
+          const int nd = hf ? ((d + 1) & 7) : d, nrt = hf ? 0 : 2;
+          const float* q = Ab + nrt * 16 * ST_LDA + 8 * nd;
+          pn[0] = *(const f32x4*)(q);
+          pn[1] = *(const f32x4*)(q + 128);
+          pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+          pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+        }
+        const int rt = 2 * hf;
+        acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
+        if (do_book) {  // half-step u = 2d + hf books slot (row tile u & 3, register u >> 2): feature tile 0, then 1
+          const int u = 2 * d + hf, rtb = u & 3, q = u >> 2;
+          book(o[0][rtb][q], 2 * io, m1[rtb][q], bc[rtb][q], m2[rtb][q]);
+          book(o[1][rtb][q], 2 * io + 1, m1[rtb][q], bc[rtb][q], m2[rtb][q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto book_all = [&](const f32x4 (&o)[2][4], int io) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        book(o[0][rt][q], 2 * io, m1[rt][q], bc[rt][q], m2[rt][q]);
+        book(o[1][rt][q], 2 * io + 1, m1[rt][q], bc[rt][q], m2[rt][q]);
+      }
+  };
+  f32x4 A[2][4], B[2][4];
+  if (cnt > 0) {
+    block(A, 0, A, 0, false);
+    int i = 1;
+    for (; i + 1 < cnt; i += 2) {
+      block(B, i, A, i - 1, true);
+      block(A, i + 1, B, i, true);
+    }
+    if (i < cnt) {
+      block(B, i, A, i - 1, true);
+      book_all(B, i);
+    } else {
+      book_all(A, cnt - 1);
+    }
+  }
+  if (bad && a.range_flag) *a.range_flag = 1;
+  // (best, column, second): the 4 slots of a lane, then the 4 lanes (g) of a row, then the 4 waves through LDS
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    Top2 t = {-INFINITY, 0x7fffffff, -INFINITY};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Top2 u;
+      u.m1 = m1[rt][q];
+      const int code = bc[rt][q];
+      u.i1 = u.m1 == -INFINITY ? 0x7fffffff : ((b0 + wave + 4 * (code >> 1)) << 5) + 16 * (code & 1) + 4 * g + q;
+      u.m2 = m2[rt][q];
+      t = top2_merge(t, u);
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      Top2 u;
+      u.m1 = __shfl_xor(t.m1, o, 64);
+      u.i1 = __shfl_xor(t.i1, o, 64);
+      u.m2 = __shfl_xor(t.m2, o, 64);
+      t = top2_merge(t, u);
+    }
+    if (g == 0) {
+      float* p = red + (wave * 64 + 16 * rt + r16) * 4;
+      p[0] = t.m1;
+      p[1] = __int_as_float(t.i1);
+      p[2] = t.m2;
+    }
+  }
+  __syncthreads();
+  if (tid < 64 && m0 + tid < n) {
+    Top2 t = {red[tid * 4 + 0], __float_as_int(red[tid * 4 + 1]), red[tid * 4 + 2]};
+    for (int w = 1; w < 4; ++w) {
+      Top2 u = {red[(w * 64 + tid) * 4 + 0], __float_as_int(red[(w * 64 + tid) * 4 + 1]), red[(w * 64 + tid) * 4 + 2]};
+      t = top2_merge(t, u);
+    }
+    a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m1, __int_as_float(t.i1), t.m2, 0.0f);
+  }
+}
+static int launch_rp_argmax16(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+  ST_ENSURE_LDS((rp_argmax16_kernel<0>), RP_LDS);
+  if (n_bound <= 0) return ST_OK;
+  hipLaunchKernelGGL((rp_argmax16_kernel<0>), dim3((n_bound + 63) / 64, splits), dim3(256), RP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
 template <int EPI>
 static int launch_rp_lin_pipelined(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
   ST_ENSURE_LDS((rp_lin_kernel<EPI>), RP_LDS);
@@ -1502,6 +1714,10 @@ static int launch_rp_lin_pipelined(const GemmArgs& a, int n_bound, int splits, h
 static inline int rp_nw(int fmt, int nw_f32) { return fmt == ST_GEMM_F16X3 ? 4 : nw_f32; }
 template <int EPI, int NW = 4>
 static int launch_rp(const GemmArgs& a, int n_bound, int splits, hipStream_t st) {
+  if (EPI == EPI_ARGMAX && a.fmt == ST_GEMM_F16X3 && a.colpad) {
+    rp_ab_env();
+    if (rp_argmax_shape16) return launch_rp_argmax16(a, n_bound, splits, st);
+  }
   return a.fmt == ST_GEMM_F16X3 ? launch_rp_t<EPI, 4, true>(a, n_bound, splits, st)
                                 : launch_rp_t<EPI, NW, false>(a, n_bound, splits, st);
 }

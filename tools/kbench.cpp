@@ -204,13 +204,32 @@ int main(int argc, char** argv) {
     t = timeit([&] { hipLaunchKernelGGL(qkv_floor_kernel, dim3((n + 63) / 64), dim3(256), 0, st, x, q, n); }, 10);
     printf("qkv memory floor (read [n,256], write [n,768], no arithmetic) n=%d: %8.1f us  %.2f TB/s\n", n, t * 1e6, (double)n * 4096 / t / 1e12);
   }
-  if (want('g')) {  // generator
+  if (want('g')) {  // generator (exact argmax); argv[5] = rows of the launch if not n (the redo pass sees few rows and many splits)
     GemmArgs g = {};
     g.fmt = g_fmt;
-    g.X = x; g.n_host = n; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
-    const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(n, V, 16);
-    t = timeit([&] { launch_rp<EPI_ARGMAX>(g, n, sp, st); });
-    printf("generator  n=%d splits=%d: %8.1f us %6.1f TF\n", n, sp, t * 1e6, 2.0 * n * 256 * V / t / 1e12);
+    const int ng = argc > 5 ? atoi(argv[5]) : n;
+    g.X = x; g.n_host = ng; g.ln_a = ln_a; g.ln_b = ln_b; g.W = wg_p; g.bias = bias; g.N = V; g.partial = partial;
+    const int sp = (argc > 2 && atoi(argv[2]) > 0) ? atoi(argv[2]) : rp_splits(ng, V, 16);
+    t = timeit([&] { launch_rp<EPI_ARGMAX>(g, ng, sp, st); });
+    printf("generator  n=%d splits=%d: %8.1f us %6.1f TF\n", ng, sp, t * 1e6, 2.0 * ng * 256 * V / t / 1e12);
+    if (g_fmt == ST_GEMM_F16X3) {
+      std::vector<float4> pa((size_t)ng * sp), pb(pa.size());
+      CK(hipMemcpy(pa.data(), partial, pa.size() * 16, hipMemcpyDeviceToHost));
+      float* colpad;
+      CK(hipMalloc(&colpad, rp_screen_colpad_floats(V) * 4));
+      launch_rp_screen_colpad(g.bias, nullptr, V, colpad, st);
+      g.colpad = colpad;
+      const double t16 = timeit([&] { launch_rp<EPI_ARGMAX>(g, ng, sp, st); });
+      printf("generator 16x16x32 n=%d splits=%d: %8.1f us %6.1f TF  (x %.3f)\n", ng, sp, t16 * 1e6, 2.0 * ng * 256 * V / t16 / 1e12, t16 / t);
+      CK(hipMemcpy(pb.data(), partial, pb.size() * 16, hipMemcpyDeviceToHost));
+      size_t di = 0;
+      double dm = 0;
+      for (size_t i = 0; i < pa.size(); ++i) {
+        di += memcmp(&pa[i].y, &pb[i].y, 4) != 0;
+        dm = fmax(dm, fmax(fabs((double)pa[i].x - pb[i].x), fabs((double)pa[i].z - pb[i].z)));
+      }
+      printf("  partials against the 32x32x16 form: %zu of %zu best columns differ, max |best / second difference| %.3g\n", di, pa.size(), dm);
+    }
   }
   if (want('s') && g_fmt == ST_GEMM_F16X3) {  // generator screening pass (one product)
     GemmArgs g = {};
