@@ -625,6 +625,8 @@ extern "C" int st_gemm_argmax(const float* h, const float* ln_a, const float* ln
   gg.fmt = gemm_format;
   gg.X = h; gg.n_host = n; gg.ln_a = ln_a; gg.ln_b = ln_b; gg.W = W; gg.bias = b; gg.N = V;
   gg.partial = (float4*)scratch;
+  // a vocabulary of whole 32-column blocks needs no padded bias copy: the 16x16x32 kernel can read b itself
+  if (gemm_format == ST_GEMM_F16X3 && V % 32 == 0 && ((size_t)b & 15) == 0) gg.colpad = b;
   ST_TRY(launch_rp<EPI_ARGMAX>(gg, n, ST_ARGMAX_SPLITS, st));
   hipLaunchKernelGGL(argmax_merge_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float4*)scratch,
                      ST_ARGMAX_SPLITS, n, ids, best, gap);

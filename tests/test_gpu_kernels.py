@@ -55,7 +55,9 @@ def relerr(a, b):
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
-@pytest.mark.parametrize("n,V,ln", [(1, 9339, True), (63, 9339, False), (65, 19724, True), (300, 100, True), (128, 256, False)])
+# V % 32 == 0 with the f16x3 format: rp_argmax16_kernel (the decoder's exact-argmax kernel), otherwise rp_gemm_kernel<EPI_ARGMAX>
+@pytest.mark.parametrize("n,V,ln", [(1, 9339, True), (63, 9339, False), (65, 19724, True), (300, 100, True), (128, 256, False),
+                                    (777, 9344, True), (5, 32, True), (200, 1024, False)])
 def test_gemm_argmax(dev, n, V, ln, fmt):
     from style_transfer_amd import ops
     rng = np.random.default_rng(n + V)
@@ -79,10 +81,10 @@ def test_gemm_argmax(dev, n, V, ln, fmt):
     assert np.abs(gap - ref_gap).max() < 1e-4
 
 
-def test_gemm_argmax_ties_pick_lowest_index(dev):
+@pytest.mark.parametrize("V", [1000, 1024])  # 1024: rp_argmax16_kernel in the f16x3 format
+def test_gemm_argmax_ties_pick_lowest_index(dev, V):
     """torch.max on CPU returns the first maximal index (model.py:292); exact ties must do the same."""
     from style_transfer_amd import ops
-    V = 1000
     h = torch.zeros(70, 256, device=dev)
     h[:, 0] = 1.0
     W = torch.zeros(V, 256, device=dev)

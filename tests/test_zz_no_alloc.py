@@ -3,6 +3,7 @@ st_gemm_argmax (caller-owned scratch) through the C-ABI: identical ids / best / 
 second with a smaller input (the shared scratch keeps the first call's contents), in both GEMM formats; sizes
 beyond the static scratch are rejected."""
 import ctypes as C
+import gc
 
 import numpy as np
 import pytest
@@ -41,6 +42,7 @@ def test_noalloc_argmax_matches_scratch_version_twice(dev, fmt):
     for h, (rid, rbest, rgap) in zip(hs, refs):   # two calls in a row, the second smaller
         n = h.shape[0]
         ids.fill_(-7); best.fill_(float("nan")); gap.fill_(float("nan"))
+        gc.collect()   # tensors of earlier tests that die during the call would move the counter too
         mem0 = torch.cuda.memory_allocated(dev)
         ops.gemm_argmax_noalloc(h, packed, b, ids, best, gap, ln_a, ln_b, gemm_format=fmt)
         assert torch.cuda.memory_allocated(dev) == mem0
