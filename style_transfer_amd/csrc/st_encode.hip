@@ -162,6 +162,255 @@ __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// QKV projection + self-attention of one encoder layer in ONE kernel (f16x3 format, sentences of <= 16 tokens, i.e.
+// all of yelp): q, k, v never go to HBM.  The two-kernel form (rp_lin16_kernel<EPI_BIAS> + enc_attn16_kernel) writes
+// 3 KB per token and reads them back: 28 + 18 ms of a 354 ms bench step, with the QKV kernel running at memory time PLUS
+// MFMA time.
+// A workgroup OWNS the sentences whose first row lies in its window of `win` = 65 - max_sent_len rows (>= 49): their rows
+// [r0, r1) are at most win - 1 + max_sent_len = 64, one panel, no sentence is split and none is computed twice
+// (enc_window_kernel gives every window its first sentence).  Per head h: the 192 columns [q_h | k_h | v_h] of the
+// stacked projection go through the MFMAs (wave w: 48 columns = 3 feature tiles, row tiles {0,1} or {2,3}; W as the A
+// operand, K-permuted panel rows, three products per term, as rp_lin16_kernel) into an f32 LDS buffer, then the eight
+// waves run the attention of 4 query rows at a time: lane (qs, j) scores key j of query qs (64-term dot product from
+// LDS; rows of one sentence broadcast), softmax over the 16 lanes of a DPP row, the probabilities pass through a small
+// LDS buffer and lane (qs, t) accumulates dims 4t..4t+3 of the output.  The next head's MFMAs start before the
+// slower waves have finished their queries (the barrier sits in front of the epilogue stores, not in front of the loop).
+// ------------------------------------------------------------------------------------------------
+#define EQA_HB 196  /* head buffer row stride in floats: [q 64 | k 64 | v 64] + 4 */
+#define EQA_LDS ((64 * ST_LDA + 64 * EQA_HB + 8 * 64 + 2 * 64) * 4)
+
+// first_sent[w] = first sentence whose first row is >= w * win, for w = 0 .. n_win (first_sent[n_win] = n_sent)
+__global__ __launch_bounds__(256) void enc_window_kernel(const int32_t* __restrict__ off, int n_sent, int win, int n_win,
+                                                         int32_t* __restrict__ first_sent) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s > n_sent) return;
+  const int wa = s < n_sent ? min(off[s] / win, n_win) : n_win;        // window of this sentence's first row (sentinel: n_win)
+  const int wb = s > 0 ? min(off[s - 1] / win, n_win) : -1;            // window of the previous sentence's first row
+  for (int w = wb + 1; w <= wa; ++w) first_sent[w] = s;                // windows (wb, wa] start with sentence s
+}
+
+__device__ __forceinline__ float row16_max(float v) {
+#define ST_ROW_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
+  ST_ROW_MAX(0x121);  // row_ror:1
+  ST_ROW_MAX(0x122);
+  ST_ROW_MAX(0x124);
+  ST_ROW_MAX(0x128);
+#undef ST_ROW_MAX
+  return v;
+}
+
+struct EqaArgs {
+  const float* x;          // [R,256]
+  const int32_t* off;      // [n_sent + 1]
+  const int32_t* first_sent;  // [n_win + 1]
+  const float *ln_a, *ln_b;
+  const float* W;          // packed [768,256], f16x3
+  const float* bias;       // [768]
+  float* att;              // [R,256]
+  int* range_flag;
+  int R, n_sent, n_win;
+};
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(512) void enc_qkv_attn16_kernel(EqaArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                      // [64][ST_LDA] LayerNorm'ed split panel
+  float* hb = smem + 64 * ST_LDA;        // [64][EQA_HB] q | k | v of the current head, f32
+  float* pbuf = hb + 64 * EQA_HB;        // [8 waves][4 queries][16] probabilities
+  int* rfirst = (int*)(pbuf + 8 * 64);   // [64] first panel row of the row's sentence
+  int* rlen = rfirst + 64;               // [64] length of the row's sentence
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  // persistent over windows (one workgroup per CU: 117 KiB of LDS): the next window's rows travel from HBM into
+  // registers while this window computes
+  struct Win { int s_lo, s_hi, r0, nr; };
+  auto window = [&](int p) -> Win {
+    Win w = {0, 0, 0, 0};
+    if (p < a.n_win) {
+      w.s_lo = a.first_sent[p];
+      w.s_hi = a.first_sent[p + 1];
+      if (w.s_lo < w.s_hi) {
+        w.r0 = a.off[w.s_lo];
+        w.nr = a.off[w.s_hi] - w.r0;
+        if (w.nr < 0 || w.nr > 64) w.nr = 0;  // (enc_check_len_kernel has flagged longer sentences)
+      }
+    }
+    return w;
+  };
+  f32x4 xr[8];
+  auto xload = [&](const Win& w) {
+    if (w.nr > 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int f = tid + i * 512;
+        xr[i] = *(const f32x4*)(a.x + (size_t)(w.r0 + min(f >> 6, w.nr - 1)) * 256 + (f & 63) * 4);
+      }
+    }
+  };
+  const int w4 = wave & 3, rh = wave >> 2;  // 48 columns of the head's 192, row tiles 2rh and 2rh + 1
+  const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, 24 * 32768, 0x00020000);
+  // feature tile f of head h: global column, and the byte offset of its hi fragments inside the packed image
+  auto gcol = [&](int h, int f) -> int {
+    const int c = 48 * w4 + 16 * f;
+    return 256 * (c >> 6) + 64 * h + (c & 63);
+  };
+  auto wofs = [&](int h, int f) -> int {
+    const int c = gcol(h & 3, f);
+    return (c >> 5) * 32768 + ((c >> 4) & 1) * 256;
+  };
+  auto wfetch = [&](int h, int d, f32x4 (&dst)[6]) {
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const int o = wofs(h, f) + d * 4096;
+      dst[2 * f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl, o, 0));
+      dst[2 * f + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1024, o, 0));
+    }
+  };
+  const float* Pb = As + (32 * rh + r16) * ST_LDA + rp16_frag_pos(0, g);
+  const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+  const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+  int bad = 0;
+  f32x4 rw[2][6];
+  wfetch(0, 0, rw[0]);
+  wfetch(0, 1, rw[1]);
+  Win cur = window(blockIdx.x);
+  xload(cur);
+  for (int p = blockIdx.x; p < a.n_win; p += gridDim.x) {
+    const Win nxt = window(p + gridDim.x);
+    const int r0 = cur.r0, nr = cur.nr;
+    if (nr > 0) {  // (uniform)
+      // ---- panel rows -> LDS, sentence bounds, LayerNorm, f16 split (K-permuted rows) ----
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int f = tid + i * 512;
+        *(f32x4*)(As + (f >> 6) * ST_LDA + (f & 63) * 4) = xr[i];
+      }
+      if (tid < 64) {
+        rfirst[tid] = 0;
+        rlen[tid] = 0;
+      }
+      __syncthreads();
+      xload(nxt);  // in flight during this window's products
+      for (int s = cur.s_lo + tid; s < cur.s_hi; s += 512) {
+        const int b = a.off[s] - r0, e = a.off[s + 1] - r0;
+        for (int r = b; r < e; ++r) {
+          rfirst[r] = b;
+          rlen[r] = e - b;
+        }
+      }
+#pragma unroll 4
+      for (int rr = 0; rr < 8; ++rr) {
+        float* row = As + (wave * 8 + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
+        panel_store4_nb16(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
+      }
+      __syncthreads();
+      for (int h = 0; h < 4; ++h) {
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          const f32x4 b4 = *(const f32x4*)(a.bias + gcol(h, f) + 4 * g);
+          acc[f][0] = b4;
+          acc[f][1] = b4;
+        }
+        f32x4 pn[4];
+        pn[0] = *(const f32x4*)(Pb);
+        pn[1] = *(const f32x4*)(Pb + 128);
+        pn[2] = *(const f32x4*)(Pb + 16 * ST_LDA);
+        pn[3] = *(const f32x4*)(Pb + 16 * ST_LDA + 128);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const int sl = d & 1;
+          h8 wh[3], wo[3];
+#pragma unroll
+          for (int f = 0; f < 3; ++f) {
+            wh[f] = as_h8(rw[sl][2 * f]);
+            wo[f] = as_h8(rw[sl][2 * f + 1]);
+          }
+          if (d + 2 < 8)
+            wfetch(h, d + 2, rw[sl]);
+          else
+            wfetch(h + 1, d + 2 - 8, rw[sl]);  // the ring never drains: head 4 = head 0 of the next window
+          const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+          if (d < 7) {
+            const float* q = Pb + 8 * (d + 1);
+            pn[0] = *(const f32x4*)(q);
+            pn[1] = *(const f32x4*)(q + 128);
+            pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+            pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+          }
+#pragma unroll
+          for (int f = 0; f < 3; ++f) {
+            acc[f][0] = mfma16x32h(wh[f], p0h, acc[f][0]);
+            acc[f][1] = mfma16x32h(wh[f], p1h, acc[f][1]);
+          }
+#pragma unroll
+          for (int f = 0; f < 3; ++f) {
+            acc[f][0] = mfma16x32h(wo[f], p0h, acc[f][0]);
+            acc[f][1] = mfma16x32h(wo[f], p1h, acc[f][1]);
+          }
+#pragma unroll
+          for (int f = 0; f < 3; ++f) {
+            acc[f][0] = mfma16x32h(wh[f], p0l, acc[f][0]);
+            acc[f][1] = mfma16x32h(wh[f], p1l, acc[f][1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (h > 0) __syncthreads();  // every wave is done with the previous head's attention: hb may be overwritten
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            *(f32x4*)(hb + (32 * rh + 16 * j + r16) * EQA_HB + 48 * w4 + 16 * f + 4 * g) = acc[f][j];
+        __syncthreads();  // q | k | v of head h complete
+        // ---- attention of head h: 4 query rows per wave and pass ----
+        const int qs = lane >> 4, j = lane & 15;
+        for (int gi = wave; 4 * gi < nr; gi += 8) {
+          const int qrow = 4 * gi + qs;
+          const bool vq = qrow < nr;
+          const int first = vq ? rfirst[qrow] : 0, len = vq ? rlen[qrow] : 0;
+          const bool valid = j < len;
+          const float* qp = hb + qrow * EQA_HB;
+          const float* kp = hb + min(first + j, 63) * EQA_HB + 64;
+          float sc = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            const f32x4 qv = *(const f32x4*)(qp + 4 * c), kv = *(const f32x4*)(kp + 4 * c);
+            sc = fmaf(qv.x, kv.x, fmaf(qv.y, kv.y, fmaf(qv.z, kv.z, fmaf(qv.w, kv.w, sc))));
+          }
+          sc = valid ? sc * 0.125f : -INFINITY;  // / sqrt(d_k)
+          const float m = row16_max(sc);
+          const float e = valid ? __expf(sc - m) : 0.0f;
+          const float sum = row16_sum(e);
+          float* pw = pbuf + wave * 64;
+          pw[lane] = len > 0 ? e / sum : 0.0f;
+          __builtin_amdgcn_wave_barrier();
+          f32x4 o4 = {0, 0, 0, 0};
+          const float* vp = hb + first * EQA_HB + 128 + 4 * j;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 p4 = *(const f32x4*)(pw + 16 * qs + 4 * c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int kk = min(first + 4 * c + u, 63) - first;  // keys beyond the sentence carry p = 0
+              o4 += p4[u] * *(const f32x4*)(vp + kk * EQA_HB);
+            }
+          }
+          if (vq) *(f32x4*)(a.att + (size_t)(r0 + qrow) * 256 + 64 * h + 4 * j) = o4;
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __syncthreads();  // the last head's attention is done before the next window overwrites the panel and hb
+    } else {
+      xload(nxt);
+    }
+    cur = nxt;
+  }
+  if (bad && a.range_flag) *a.range_flag = 1;
+}
+
 // latent[s] = sum over the sentence's rows of sigmoid(LayerNorm_f(x[row]))   (model.py:236-240)
 __global__ __launch_bounds__(256) void enc_latent_kernel(const float* __restrict__ x, const int32_t* __restrict__ off,
                                                          int n_sent, const float* __restrict__ ln_a,
@@ -197,7 +446,8 @@ extern "C" size_t st_encode_workspace_bytes(const StEncoderWeights* w, int n_row
   if (!w || n_rows <= 0) return 0;
   (void)n_sent;
   return enc_align((size_t)n_rows * 256 * 4) * 2 + enc_align((size_t)n_rows * 768 * 4) +
-         enc_align((size_t)n_rows * w->d_ff * 4) + 256;  // + the f16-range flag
+         enc_align((size_t)n_rows * w->d_ff * 4) + 256 +  // + the f16-range flag
+         enc_align(((size_t)n_rows / 49 + 2) * 4);       // + first sentence of every ownership window (fused QKV + attention)
 }
 
 extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens, const int32_t* tok_pos,
@@ -228,9 +478,18 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
   float* att = (float*)base; base += enc_align((size_t)n_rows * 256 * 4);
   float* qkv = (float*)base; base += enc_align((size_t)n_rows * 768 * 4);
   float* h = (float*)base; base += enc_align((size_t)n_rows * w->d_ff * 4);
-  int* range_flag = (int*)base;
+  int* range_flag = (int*)base; base += 256;
+  int32_t* first_sent = (int32_t*)base;
   ST_HIP(hipMemsetAsync(range_flag, 0, 2 * sizeof(int), st));
   const int R = n_rows;
+  // fused QKV + attention (f16x3, every sentence <= 16 tokens): ownership windows of 65 - max_sent_len >= 49 rows
+  static const bool ab_unfused = getenv("ST_AB_ENC_UNFUSED") != nullptr;  // A/B: the two-kernel form
+  const bool fused = w->gemm_format == ST_GEMM_F16X3 && max_sent_len <= 16 && max_sent_len >= 1 && !ab_unfused;
+  const int win = 65 - (max_sent_len < 1 ? 1 : max_sent_len), n_win = (R + win - 1) / win;
+  if (fused) {
+    ST_ENSURE_LDS((enc_qkv_attn16_kernel<0>), EQA_LDS);
+    hipLaunchKernelGGL(enc_window_kernel, dim3((n_sent + 1 + 255) / 256), dim3(256), 0, st, sent_off, n_sent, win, n_win, first_sent);
+  }
   hipLaunchKernelGGL(enc_check_len_kernel, dim3((n_sent + 255) / 256), dim3(256), 0, st, sent_off, n_sent, max_sent_len, n_rows, range_flag);
   hipLaunchKernelGGL(enc_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->emb, w->pe, tokens, tok_pos, R, w->vocab, x);
   ST_LAUNCH_CHECK();
@@ -238,26 +497,34 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     const StEncLayer& y = w->layer[l];
     ST_CHECK_ARG(y.ln0_a && y.ln0_b && y.wqkv && y.bqkv && y.wo && y.bo && y.ln1_a && y.ln1_b && y.w1 && y.b1 && y.w2 && y.b2,
                  "NULL weight pointer in encoder layer %d", l);
-    GemmArgs g = {};
-    g.fmt = w->gemm_format; g.range_flag = range_flag;
-    g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
-    g.out = qkv; g.ldo = 768;
-    const int qsplits = rp_splits(R, 768, 3, rp_nw(w->gemm_format, 8));
-    if (w->gemm_format == ST_GEMM_F16X3)
-      ST_TRY(launch_rp_lin_pipelined<EPI_BIAS>(g, R, qsplits, st));
-    else
-      ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, qsplits, st)));
-    if (w->gemm_format == ST_GEMM_F16X3)
-      hipLaunchKernelGGL(enc_attn16_kernel<true>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
-    else
-      hipLaunchKernelGGL(enc_attn16_kernel<false>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
-    if (max_sent_len > 16) {
+    if (fused) {
+      EqaArgs e = {};
+      e.x = x; e.off = sent_off; e.first_sent = first_sent; e.ln_a = y.ln0_a; e.ln_b = y.ln0_b; e.W = y.wqkv; e.bias = y.bqkv;
+      e.att = att; e.range_flag = range_flag; e.R = R; e.n_sent = n_sent; e.n_win = n_win;
+      hipLaunchKernelGGL((enc_qkv_attn16_kernel<0>), dim3(std::min(n_win, st_cu_count())), dim3(512), EQA_LDS, st, e);
+      ST_LAUNCH_CHECK();
+    } else {
+      GemmArgs g = {};
+      g.fmt = w->gemm_format; g.range_flag = range_flag;
+      g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
+      g.out = qkv; g.ldo = 768;
+      const int qsplits = rp_splits(R, 768, 3, rp_nw(w->gemm_format, 8));
       if (w->gemm_format == ST_GEMM_F16X3)
-        hipLaunchKernelGGL(enc_attn_kernel<true>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+        ST_TRY(launch_rp_lin_pipelined<EPI_BIAS>(g, R, qsplits, st));
       else
-        hipLaunchKernelGGL(enc_attn_kernel<false>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+        ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, qsplits, st)));
+      if (w->gemm_format == ST_GEMM_F16X3)
+        hipLaunchKernelGGL(enc_attn16_kernel<true>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
+      else
+        hipLaunchKernelGGL(enc_attn16_kernel<false>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
+      if (max_sent_len > 16) {
+        if (w->gemm_format == ST_GEMM_F16X3)
+          hipLaunchKernelGGL(enc_attn_kernel<true>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+        else
+          hipLaunchKernelGGL(enc_attn_kernel<false>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+      }
+      ST_LAUNCH_CHECK();
     }
-    ST_LAUNCH_CHECK();
     OFArgs of = {};
     of.fmt = w->gemm_format; of.range_flag = range_flag;
     of.att = att; of.n_host = R; of.wo = y.wo; of.bo = y.bo; of.x = x; of.ln_a = y.ln1_a; of.ln_b = y.ln1_b;

@@ -183,6 +183,34 @@ def test_encode_latent(dev, ae, ae_sd):
         assert relerr(got[i], ref) < 2e-4, (i, relerr(got[i], ref))
 
 
+@pytest.mark.parametrize("max_len", [16, 9])
+def test_encode_latent_short_sentences_fused_kernel(dev, ae, ae_sd, max_len):
+    """every sentence <= 16 tokens (all of yelp): in the f16x3 format the QKV projection and the attention of a layer run in
+    ONE kernel whose workgroups own the sentences that start in their window of 65 - max_len rows.  Many windows, sentences
+    of every length 1 .. max_len (also empty ones) in a random order, each latent against the oracle."""
+    from style_transfer_amd import ops
+    from style_transfer_amd.data import pack_sentences
+    rng = np.random.default_rng(max_len)
+    pool = [w for s_ in some_sentences(40) for w in s_]
+    sents = []
+    for i in range(260):
+        n = int(rng.integers(0, max_len + 1)) if i % 7 else max_len
+        sents.append([int(pool[int(k)]) for k in rng.integers(0, len(pool), n)])
+    tok, pos, off, mx = pack_sentences(sents)
+    assert mx == max_len and int(off[-1]) > 10 * (65 - max_len)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    got = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx).cpu().numpy()
+    worst = 0.0
+    for i, s_ in enumerate(sents):
+        if not s_:
+            assert np.abs(got[i]).max() == 0
+            continue
+        ref = O.encode_latent(ae_sd, np.asarray([s_], np.int64))[0]
+        worst = max(worst, relerr(got[i], ref))
+        assert relerr(got[i], ref) < 2e-4, (i, len(s_), relerr(got[i], ref))
+    print("fused encoder kernel, max_len %d: %d sentences, %d rows, worst relative latent error %.3g" % (max_len, len(sents), int(off[-1]), worst))
+
+
 def test_encode_latent_rejects_a_sentence_longer_than_declared(dev, ae):
     """st_encode_latent must not return ST_OK with stale attention rows when sent_off holds a sentence longer than the
     caller's max_sent_len (the attention kernels skip it): ST_EINVAL."""
