@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict
 // LDS buffer and lane (qs, t) accumulates dims 4t..4t+3 of the output.  The next head's MFMAs start before the
 // slower waves have finished their queries (the barrier sits in front of the epilogue stores, not in front of the loop).
 // ------------------------------------------------------------------------------------------------
-#define EQA_HB 196  /* head buffer row stride in floats: [q 64 | k 64 | v 64] + 4 */
-#define EQA_LDS ((64 * ST_LDA + 64 * EQA_HB + 8 * 64 + 2 * 64) * 4)
+#define EQA_LD 72  /* dwords per row of the head buffers: 64 hi halves | 64 lo halves | 8 of padding (= 8 mod 64: conflict-free b128 fragment reads) */
+#define EQA_LDS ((64 * ST_LDA + 3 * 64 * EQA_LD + 2 * 64) * 4)
 
 // first_sent[w] = first sentence whose first row is >= w * win, for w = 0 .. n_win (first_sent[n_win] = n_sent)
 __global__ __launch_bounds__(256) void enc_window_kernel(const int32_t* __restrict__ off, int n_sent, int win, int n_win,
@@ -216,10 +216,11 @@ template <int UNUSED = 0>
 __global__ __launch_bounds__(512) void enc_qkv_attn16_kernel(EqaArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* As = smem;                      // [64][ST_LDA] LayerNorm'ed split panel
-  float* hb = smem + 64 * ST_LDA;        // [64][EQA_HB] q | k | v of the current head, f32
-  float* pbuf = hb + 64 * EQA_HB;        // [8 waves][4 queries][16] probabilities
-  int* rfirst = (int*)(pbuf + 8 * 64);   // [64] first panel row of the row's sentence
-  int* rlen = rfirst + 64;               // [64] length of the row's sentence
+  float* Qs = smem + 64 * ST_LDA;        // [64 rows][EQA_LD] q of the current head, f16 hi | lo
+  float* Ks = Qs + 64 * EQA_LD;          // [64 rows][EQA_LD] k
+  float* Vt = Ks + 64 * EQA_LD;          // [64 dims][EQA_LD] v TRANSPOSED: row = dim, column = panel row (key)
+  int* slist = (int*)(Vt + 64 * EQA_LD);  // [64] the window's non-empty sentences: first panel row | length << 8
+  int* scount = slist + 64;              // their number
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
@@ -288,18 +289,12 @@ __global__ __launch_bounds__(512) void enc_qkv_attn16_kernel(EqaArgs a) {
         const int f = tid + i * 512;
         *(f32x4*)(As + (f >> 6) * ST_LDA + (f & 63) * 4) = xr[i];
       }
-      if (tid < 64) {
-        rfirst[tid] = 0;
-        rlen[tid] = 0;
-      }
+      if (tid == 0) *scount = 0;
       __syncthreads();
       xload(nxt);  // in flight during this window's products
       for (int s = cur.s_lo + tid; s < cur.s_hi; s += 512) {
         const int b = a.off[s] - r0, e = a.off[s + 1] - r0;
-        for (int r = b; r < e; ++r) {
-          rfirst[r] = b;
-          rlen[r] = e - b;
-        }
+        if (e > b && e <= 64) slist[atomicAdd(scount, 1)] = b | ((e - b) << 8);  // (at most 64: every one has a row)
       }
 #pragma unroll 4
       for (int rr = 0; rr < 8; ++rr) {
@@ -358,48 +353,96 @@ __global__ __launch_bounds__(512) void enc_qkv_attn16_kernel(EqaArgs a) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (h > 0) __syncthreads();  // every wave is done with the previous head's attention: hb may be overwritten
+        if (h > 0) __syncthreads();  // every wave is done with the previous head's attention: the head buffers may be overwritten
 #pragma unroll
-        for (int f = 0; f < 3; ++f)
+        for (int f = 0; f < 3; ++f) {
+          const int c = 48 * w4 + 16 * f;  // (wave-uniform) column inside [q | k | v]; the lane adds 4 g
+          const int d0 = (c & 63) + 4 * g;
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            *(f32x4*)(hb + (32 * rh + 16 * j + r16) * EQA_HB + 48 * w4 + 16 * f + 4 * g) = acc[f][j];
-        __syncthreads();  // q | k | v of head h complete
-        // ---- attention of head h: 4 query rows per wave and pass ----
-        const int qs = lane >> 4, j = lane & 15;
-        for (int gi = wave; 4 * gi < nr; gi += 8) {
-          const int qrow = 4 * gi + qs;
-          const bool vq = qrow < nr;
-          const int first = vq ? rfirst[qrow] : 0, len = vq ? rlen[qrow] : 0;
-          const bool valid = j < len;
-          const float* qp = hb + qrow * EQA_HB;
-          const float* kp = hb + min(first + j, 63) * EQA_HB + 64;
-          float sc = 0.0f;
+          for (int j = 0; j < 2; ++j) {
+            const int row = 32 * rh + 16 * j + r16;
+            h4 hi, lo;
+            split_f16(acc[f][j], hi, lo);
+            if ((c >> 6) < 2) {
+              _Float16* dst = (_Float16*)(((c >> 6) ? Ks : Qs) + row * EQA_LD) + d0;
+              *(h4*)dst = hi;
+              *(h4*)(dst + 64) = lo;
+            } else {
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            const f32x4 qv = *(const f32x4*)(qp + 4 * c), kv = *(const f32x4*)(kp + 4 * c);
-            sc = fmaf(qv.x, kv.x, fmaf(qv.y, kv.y, fmaf(qv.z, kv.z, fmaf(qv.w, kv.w, sc))));
-          }
-          sc = valid ? sc * 0.125f : -INFINITY;  // / sqrt(d_k)
-          const float m = row16_max(sc);
-          const float e = valid ? __expf(sc - m) : 0.0f;
-          const float sum = row16_sum(e);
-          float* pw = pbuf + wave * 64;
-          pw[lane] = len > 0 ? e / sum : 0.0f;
-          __builtin_amdgcn_wave_barrier();
-          f32x4 o4 = {0, 0, 0, 0};
-          const float* vp = hb + first * EQA_HB + 128 + 4 * j;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const f32x4 p4 = *(const f32x4*)(pw + 16 * qs + 4 * c);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int kk = min(first + 4 * c + u, 63) - first;  // keys beyond the sentence carry p = 0
-              o4 += p4[u] * *(const f32x4*)(vp + kk * EQA_HB);
+              for (int i = 0; i < 4; ++i) {
+                _Float16* dst = (_Float16*)(Vt + (d0 + i) * EQA_LD) + row;
+                dst[0] = hi[i];
+                dst[64] = lo[i];
+              }
             }
           }
-          if (vq) *(f32x4*)(a.att + (size_t)(r0 + qrow) * 256 + 64 * h + 4 * j) = o4;
-          __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();  // q | k | v^T of head h complete
+        // ---- attention of head h on the matrix cores, one sentence per wave and pass, the sentence's rows at CANONICAL
+        // tile positions (key j = row j of the A tile, whatever the sentence's place in the panel: a sentence's result
+        // does not depend on its neighbours, bit for bit).
+        //   S^T tile = K . Q^T (A = the sentence's K rows, B = its Q rows: same fragment form as a panel): lane (r16, g)
+        //   gets keys 4g .. 4g+3 of query r16; softmax over the lane's 4 values and the 4 lanes of the query;
+        //   O^T = V^T . P: the lane's own probabilities ARE its B fragment (k = 4g .. 4g+3, upper half of the k-step 0),
+        //   A = V^T rows read at the sentence's columns. ----
+        {
+          const int ns = *scount;
+          for (int si = wave; si < ns; si += 8) {
+            const int ent = slist[si], first = ent & 255, len = ent >> 8;  // (wave-uniform)
+            const int row = min(first + r16, 63);                          // rows beyond the sentence: masked below
+            const float* qb = Qs + row * EQA_LD + 4 * g;
+            const h8 qh0 = as_h8(*(const f32x4*)(qb)), qh1 = as_h8(*(const f32x4*)(qb + 16));
+            const h8 ql0 = as_h8(*(const f32x4*)(qb + 32)), ql1 = as_h8(*(const f32x4*)(qb + 48));
+            const float* kb = Ks + row * EQA_LD + 4 * g;
+            const h8 kh0 = as_h8(*(const f32x4*)(kb)), kh1 = as_h8(*(const f32x4*)(kb + 16));
+            const h8 kl0 = as_h8(*(const f32x4*)(kb + 32)), kl1 = as_h8(*(const f32x4*)(kb + 48));
+            f32x4 S = {0, 0, 0, 0};
+            S = mfma16x32h(kh0, qh0, S);
+            S = mfma16x32h(kh1, qh1, S);
+            S = mfma16x32h(kl0, qh0, S);
+            S = mfma16x32h(kl1, qh1, S);
+            S = mfma16x32h(kh0, ql0, S);
+            S = mfma16x32h(kh1, ql1, S);
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              S[i] = 4 * g + i < len ? S[i] * 0.125f : -INFINITY;  // / sqrt(d_k); keys beyond the sentence
+              m = fmaxf(m, S[i]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));  // (key 0 always exists: m is finite)
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              S[i] = 4 * g + i < len ? __expf(S[i] - m) : 0.0f;
+              sum += S[i];
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            h4 ph, pl;
+            split_f16(S * (1.0f / sum), ph, pl);
+            const h4 z4 = {0, 0, 0, 0};
+            const h8 bh = __builtin_shufflevector(ph, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+            const h8 bl = __builtin_shufflevector(pl, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              const _Float16* vb = (const _Float16*)(Vt + (16 * dt + r16) * EQA_LD);
+              h8 ah, al;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int key = min(first + 4 * g + i, 63);
+                ah[i] = vb[key];
+                al[i] = vb[64 + key];
+                ah[4 + i] = (_Float16)0.0f;
+                al[4 + i] = (_Float16)0.0f;
+              }
+              f32x4 o = {0, 0, 0, 0};
+              o = mfma16x32h(ah, bh, o);
+              o = mfma16x32h(al, bh, o);
+              o = mfma16x32h(ah, bl, o);
+              if (r16 < len) *(f32x4*)(a.att + (size_t)(r0 + first + r16) * 256 + 64 * h + 16 * dt + 4 * g) = o;
+            }
+          }
         }
       }
       __syncthreads();  // the last head's attention is done before the next window overwrites the panel and hb
