@@ -2766,7 +2766,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int f = tid + i * 512;
-      panel_store4_nb(P1 + (f >> 6) * ST_LDA, f & 63, attr[i], bad);
+      panel_store4_nb16(P1 + (f >> 6) * ST_LDA, f & 63, attr[i], bad);  // K-permuted rows: conflict-free fragment reads
     }
   };
   f32x4 ax[2][4], px[2][4], pc[2][4];  // [feature tile][row tile]
@@ -2833,8 +2833,8 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   TSTAMP(0);
   __syncthreads();
   TSTAMP(1);
-  const float* A1 = P1 + r16 * ST_LDA + 4 * g;  // panel fragment base (row tile 0, double step 0, hi)
-  const float* A2 = P2 + r16 * ST_LDA + 4 * g;
+  const float* A1 = P1 + r16 * ST_LDA + rp16_frag_pos(0, g);  // panel fragment base (row tile 0, double step 0, hi)
+  const float* A2 = P2 + r16 * ST_LDA + rp16_frag_pos(0, g);
   // One pass over K = 256: acc[ft][rt] += W[features of tile ft] . panel[rows of tile rt]^T.  With EPI the accumulators
   // o of the previous hidden chunk are converted (ReLU, f16 split) and written to P2 in the MFMAs' shadow.
   _Float16* H2 = (_Float16*)P2;
@@ -2846,7 +2846,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
     bad |= !(mx <= 65504.0f);
     h4 hi, lo;
     split_f16(v, hi, lo);
-    _Float16* dst = H2 + (size_t)(16 * rt + r16) * (2 * ST_LDA) + fcol + 16 * ft;
+    _Float16* dst = H2 + (size_t)(16 * rt + r16) * (2 * ST_LDA) + 2 * rp16_quad_pos((fcol + 16 * ft) >> 2);  // hidden unit = k of FFN2
     *(h4*)dst = hi;
     *(h4*)(dst + 256) = lo;
   };
@@ -2869,7 +2869,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
         const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
         if (!(d == 7 && hf == 1)) {
           const int nd = hf ? d + 1 : d, nrt = hf ? 0 : 2;
-          const float* q = Pb + nrt * 16 * ST_LDA + 16 * nd;
+          const float* q = Pb + nrt * 16 * ST_LDA + 8 * nd;
           pn[0] = *(const f32x4*)(q);
           pn[1] = *(const f32x4*)(q + 128);
           pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
@@ -2914,7 +2914,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
 #pragma unroll
   for (int rr = 0; rr < 8; ++rr) {
     float* row = P1 + (wave * 8 + rr) * ST_LDA;
-    panel_store4_nb(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
+    panel_store4_nb16(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
   }
   {
     const f32x4 b20 = *(const f32x4*)(a.b2 + fcol), b21 = *(const f32x4*)(a.b2 + fcol + 16);
