@@ -139,6 +139,23 @@ __global__ __launch_bounds__(256) void qkv_floor_kernel(const float* x, float* o
   }
 }
 
+// Pure-read floor: every wave streams 16-byte loads over a large f32 array and keeps a sum (nothing stored).
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_floor_kernel(const float* x, size_t n4, float* out) {
+  const f32x4* p = (const f32x4*)x;
+  f32x4 acc = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+    f32x4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc += v[u];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 1.2345f) out[threadIdx.x] = acc.x;
+}
+
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 65536;
   g_fmt = argc > 3 ? atoi(argv[3]) : ST_GEMM_F32;  // kbench <rows> <generator splits, 0 = auto> <format>
@@ -198,6 +215,13 @@ int main(int argc, char** argv) {
       for (int j = 0; j < 5; ++j)
         printf("16x16x32 MFMA loop + %d v_max3_f32 per MFMA, %d waves per SIMD: %8.1f us  %7.1f TF  (x %.3f)\n", j, wg_threads / 256,
                tv[j] * 1e6, fl / tv[j] / 1e12, tv[j] / tv[0]);
+    }
+  }
+  if (want('r')) {  // pure-read floor over the q output buffer ([n,768] f32)
+    const size_t n4 = (size_t)n * 768 / 4;
+    for (int wgs : {1024, 2048, 4096, 8192}) {
+      t = timeit([&] { hipLaunchKernelGGL(read_floor_kernel<8>, dim3(wgs), dim3(256), 0, st, q, n4, x); }, 10);
+      printf("pure read, %d workgroups x 256 threads, 8 x 16 B in flight per thread, %.2f GB: %8.1f us  %.2f TB/s\n", wgs, n4 * 16 / 1e9, t * 1e6, n4 * 16.0 / t / 1e12);
     }
   }
   if (want('m')) {  // memory floor of the QKV projection
