@@ -2794,8 +2794,6 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   };
   att_load(m0);
   idx_stage(m0);
-  const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
-  const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
   f32x4 b1n[2];  // FFN1 bias of this lane's 8 hidden units in the coming chunk
   auto b1_fetch = [&](int c) {
     b1n[0] = *(const f32x4*)(a.b1 + (c * 8 + wave) * 32 + 4 * g);
@@ -2903,6 +2901,10 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   if (m0 + mstride < n) idx_stage(m0 + mstride);  // read by resid_load in the last chunk, many barriers from here
   __syncthreads();  // every wave is done reading the attention panel
   TSTAMP(3);
+  // (the LayerNorm gains are fetched per panel - L2 hits, the address hangs on the opaque lane - instead of living in 8
+  // registers through the whole loop: the kernel sits at its 256-register limit)
+  const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+  const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
   // ---- x1 -> P1 (f32), LayerNorm + split in place ----
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft)
