@@ -102,23 +102,68 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def self_launch(a, argv):
+def self_launch(a, argv, poll_s=0.2, grace_s=10.0):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start one fresh worker process per GPU (before
-    this process has made any GPU call), with the rendezvous variables torch.distributed.run would set; rank 0 prints the
-    JSON line on the inherited stdout."""
-    import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+    this process has made any GPU call); rank 0 prints the JSON line on the inherited stdout.  The workers rendezvous
+    through a FILE store in a private temporary directory (no port to lose to another process).  The children are
+    polled: when any of them exits non-zero the others are terminated (then killed) and that return code is passed on,
+    so a dead worker cannot leave its siblings, and this launcher, waiting in a collective."""
+    import shutil
+    import tempfile
+    td = tempfile.mkdtemp(prefix="st_bench_rdzv_")
+    procs = {}
+    try:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                       ST_BENCH_INIT_FILE=os.path.join(td, "store"))
+            for k in ("MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            procs[r] = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env)
+        rc = 0
+        live = dict(procs)
+        while live and rc == 0:
+            for r, p in list(live.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del live[r]
+                if code != 0:
+                    rc = code if code > 0 else 128 - code       # killed by signal s: 128 + s, as a shell reports it
+                    print("[bench] rank %d exited with %d: stopping the other %d workers" % (r, code, len(live)),
+                          file=sys.stderr, flush=True)
+                    break
+            if live and rc == 0:
+                time.sleep(poll_s)
+        if live:                                                # a sibling failed: nobody is left to finish the collectives
+            for p in live.values():
+                p.terminate()
+            end = time.monotonic() + grace_s
+            for p in live.values():
+                try:
+                    p.wait(timeout=max(0.0, end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        return rc
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def init_group(backend, world, rank, dev=None):
+    """One rendezvous for every N > 1 path of this file: torch.distributed.run's environment (MASTER_ADDR / MASTER_PORT),
+    or the file store self_launch names; a FINITE timeout, so that a rank whose peer died fails instead of waiting."""
+    import datetime
+    import torch.distributed as dist
+    kw = dict(timeout=datetime.timedelta(seconds=float(os.environ.get("ST_BENCH_TIMEOUT_S", "600"))))
+    f = os.environ.get("ST_BENCH_INIT_FILE")
+    if f:
+        kw.update(init_method="file://" + f, rank=rank, world_size=world)
+    if backend == "nccl":
+        kw["device_id"] = dev
+    dist.init_process_group(backend, **kw)
 
 
 def algorithmic_flops(ae, B_total, units, enc_rows, enc_sq, kp, kn, work):
@@ -176,7 +221,7 @@ def simloss_main(a):
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        init_group("nccl", world, rank, dev)
     B, views, tau = a.simloss_batch, 11, 0.1
     assert B % (32 * world) == 0
     b = B // world
@@ -257,8 +302,11 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
     if a.dry_run:
+        die = os.environ.get("ST_BENCH_TEST_DIE_RANK")          # tests: this rank dies before the rendezvous
+        if die is not None and int(die) == rank:
+            sys.exit(3)
         if world > 1:
-            dist.init_process_group("gloo")
+            init_group("gloo", world, rank)
             dist.barrier()
         t0 = time.perf_counter()
         time.sleep(0.01 * (rank + 1))
@@ -285,10 +333,7 @@ def main(argv=None):
     dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        init_group(backend, world, rank, dev)
 
     # yelp shape: V = 9339; amazon shape: V = 19724 with its own surrogate AE (no amazon weights ship at all)
     ae_file = os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)
@@ -448,6 +493,68 @@ def main(argv=None):
                                    "log text (st_format_attack_log) -> file (%.0f MB), prefetch and drain threads overlapped "
                                    "with compute" % (len(big), B, nbytes / 1e6))
 
+    # ---- N > 1: what BASELINE config 4 names ("... with final all-gather"): every rank streams its shard through the
+    # product pipeline (host token arrays -> pack -> H2D -> attack -> lean records), the records of all ranks go to rank 0
+    # (pipeline.gather_to_rank0: RCCL send / recv over xGMI), rank 0 formats the log in global order and writes the file.
+    # Rank 0 knows every rank's origins, as every rank of the CLI holds the whole input file.
+    if world > 1 and not a.no_side_runs and not a.fixed_steps:
+        import contextlib
+        import tempfile
+        from style_transfer_amd.attack import LeanRecord
+        from style_transfer_amd.data import Ragged
+        from style_transfer_amd.logfmt import VocabBytes, format_attack_blocks
+        from style_transfer_amd.pipeline import gather_to_rank0, run_shard
+        n_e2e = 1 if a.same_batch else min(len(sets), 4)
+        big = AttackSet(Ragged.concat([s.origin_r for s in sets[:n_e2e]]), Ragged.concat([s.like_r for s in sets[:n_e2e]]),
+                        Ragged.concat([s.unlike_r for s in sets[:n_e2e]]), None, kp, kn)
+        everyone = vocab = None
+        if rank == 0:
+            with contextlib.redirect_stdout(sys.stderr):
+                id_to_word, _ = load_word_dict_info(os.path.join(GOLD, a.shape, "word_to_id.txt"), 5)
+            vocab = VocabBytes(id_to_word)
+            if a.tokens == "real":
+                origins = [real.subset([(i + 137 * r + 7919 * k) % len(real) for i in range(B)]).origin_r
+                           for r in range(world) for k in range(n_e2e)]
+            else:
+                origins = [AttackSet.synthetic(B, ae.vocab, a.shape, seed=1234 + r + 7919 * k, word_counts=counts, origins_only=True).origin_r
+                           for r in range(world) for k in range(n_e2e)]
+            assert np.array_equal(origins[0].tokens, sets[0].origin_r.tokens)
+            none = Ragged(np.zeros(0, np.int32), np.zeros(1, np.int64))
+            everyone = AttackSet(Ragged.concat(origins), none, none, None, 0, 0)
+        gdev = dev if backend == "nccl" else "cpu"
+        with tempfile.TemporaryDirectory() as td:
+            for rep in range(2):          # the first pass warms pinned buffers, threads and the RCCL channels
+                kept = []
+                sync()
+                t = time.perf_counter()
+                run_shard(runner, big, 0, len(big), B, lambda b0, b1, lean: kept.append(lean))
+                torch.cuda.synchronize(dev)
+                t_c = time.perf_counter()
+                full = gather_to_rank0(LeanRecord.cat(kept), rank, world, gdev)
+                if backend == "nccl":
+                    torch.cuda.synchronize(dev)
+                t_g = time.perf_counter()
+                nbytes = 0
+                if rank == 0:
+                    full = full.cpu()
+                    with open(os.path.join(td, "log"), "wb") as f:
+                        for block in format_attack_blocks(vocab, everyone, full, 0):
+                            f.write(memoryview(block))
+                            nbytes += block.size
+                t_w = time.perf_counter()
+                sync()
+                t_e = time.perf_counter()
+                del full, kept
+        tot_s = reduce_max(t_e - t)
+        side["end_to_end_sentences_per_s"] = world * len(big) / tot_s
+        side["compute_ms"] = reduce_max(t_c - t) * 1e3
+        side["gather_ms"] = reduce_max(t_g - t_c) * 1e3
+        side["log_write_ms"] = (t_w - t_g) * 1e3
+        side["end_to_end_note"] = ("%d sentences per rank in batches of %d through pipeline.run_shard on every rank (host token arrays -> "
+                                   "pack -> H2D -> attack), lean records of all ranks to rank 0 (gather_ms: all_gather of sizes + "
+                                   "exact-size send / recv), rank 0 formats %d sentences in global order and writes the file "
+                                   "(%.0f MB, log_write_ms); times are the max over ranks" % (len(big), B, world * len(big), nbytes / 1e6))
+
     if rank == 0:
         achieved = gen_fl.value / (gen_ms.value * 1e-3) / 1e12 if gen_ms.value > 0 else 0.0
         split = a.gemm_format == "f16x3"
@@ -487,7 +594,8 @@ def main(argv=None):
                        "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
                        "iters_per_decode": cfg.iters_per_decode, "sync_every": cfg.sync_every, "gemm_format": a.gemm_format,
                        "edit_iteration_units_per_s": tot[3] / dt,
-                       "side_runs_same_workload_one_gpu": side or None},
+                       "side_runs_same_workload_one_gpu": (side or None) if world == 1 else None,
+                       "end_to_end_with_final_gather": (side or None) if world > 1 else None},
             # the whole timed region against the MFMA roofline: executed algorithmic flops / wall time
             "whole_step": {"executed_token_steps": tot[0], "keys_attended": tot[1], "decode_jobs_executed": tot[2],
                            "decode_jobs_needed": world * B * a.steps + tot[3],

@@ -39,7 +39,9 @@ def load_ae(ref_model, args, ckpt):
     return ae
 
 
-def run_attack(subset, flags, ckpt, tag, threads):
+def run_attack(subset, flags, ckpt, tag, threads, compact_to=None):
+    """compact_to: path prefix; when given, a COMPACT record (no encoder goldens, no gradients, ids as int16) is
+    written there instead of tests/golden/attack_<tag>.npz (the whole-split goldens: yelp_full / amazon_full)."""
     torch.set_num_threads(threads)
     ref_model, ref_data, ref_sc = ref_harness.import_reference()
     flags = dict(flags)
@@ -175,6 +177,15 @@ def run_attack(subset, flags, ckpt, tag, threads):
         if kn:
             unlike[s] = ps["unlike_latent"][:, 0]
         lr[s] = ps["lr"]
+    if compact_to is not None:
+        np.savez_compressed(compact_to + ".npz", subset=np.asarray(subset, np.int32), n_iter=n_iter,
+                            init_latent=init_latent, init_ids=init_ids.astype(np.int16), init_gap=init_gap,
+                            latent=lat, ids=ids.astype(np.int16), gap=gap.astype(np.float16), gap_min=gap.min(-1),
+                            loss=loss, lr=lr, ref_seconds=np.float32(dt), ref_threads=np.int32(threads))
+        with open(compact_to + "_log.txt", "w") as f:
+            for ln in lines:
+                f.write("INFO:siamese_contrastive.py:print_and_log:1592 - " + ln + "\n")
+        return dt
     # encoder goldens: every ae_model.forward call in order (1 + kp + kn per sentence)
     Lmax = max(x.shape[1] for x in rec["enc_src"])
     enc_src = np.zeros((len(rec["enc_src"]), Lmax), np.int32)
@@ -220,10 +231,60 @@ if __name__ == "__main__":
     ap.add_argument("--what", default="main")
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--n", type=int, default=32, help="sentences per label for the main run")
+    ap.add_argument("--shard", type=int, default=0)
+    ap.add_argument("--nshards", type=int, default=1)
+    ap.add_argument("--scratch", default="/tmp/st_full_goldens")
+    ap.add_argument("--count", type=int, default=1000, help="sentences of the split to run (amazon_full: first n/2 of each label)")
     a = ap.parse_args()
     ckpt = os.path.join(GOLD, "surrogate_ae_yelp.safetensors")
     if a.what == "simloss":
         run_simloss()
+    elif a.what in ("yelp_full", "amazon_full"):
+        # The WHOLE test split (yelp: all 1000; amazon: --count of them), sharded over single-thread processes:
+        #   for k in 0..7: python oracle/make_goldens.py --what yelp_full --shard k --nshards 8 --threads 1 &
+        #   python oracle/make_goldens.py --what yelp_full --nshards 8 --shard -1      (merge)
+        task = a.what.split("_")[0]
+        if task == "amazon":
+            ckpt = os.path.join(GOLD, "surrogate_ae_amazon.safetensors")
+        half = a.count // 2
+        everything = list(range(half)) + list(range(500, 500 + half))
+        os.makedirs(a.scratch, exist_ok=True)
+        if a.shard >= 0:
+            mine = everything[a.shard::a.nshards]   # strided: every shard gets both labels and equal work
+            run_attack(mine, dict(task=task, not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt,
+                       "%s_s%d" % (a.what, a.shard), a.threads, compact_to=os.path.join(a.scratch, "%s_s%d" % (a.what, a.shard)))
+        else:
+            parts = [np.load(os.path.join(a.scratch, "%s_s%d.npz" % (a.what, k))) for k in range(a.nshards)]
+            subset = np.concatenate([p["subset"] for p in parts])
+            order = np.argsort(subset, kind="stable")
+            assert np.array_equal(subset[order], np.asarray(everything))
+            out = {k: np.concatenate([p[k] for p in parts])[order] for k in parts[0].files if parts[0][k].ndim >= 1}
+            out["ref_seconds"] = np.float32(sum(float(p["ref_seconds"]) for p in parts))
+            out["ref_threads"] = np.int32(1)
+            np.savez_compressed(os.path.join(GOLD, "attack_%s.npz" % a.what), **out)
+            # log blocks in global order: a block starts at its 'Sentence Pair.' line; the run header lines (before the
+            # first block) are taken from shard 0
+            blocks, header = {}, None
+            for k in range(a.nshards):
+                text = open(os.path.join(a.scratch, "%s_s%d_log.txt" % (a.what, k))).read().split("\n")
+                starts = [i for i, ln in enumerate(text) if "Sentence Pair." in ln]
+                if header is None:
+                    header = text[: starts[0]]
+                ids_k = parts[k]["subset"]
+                assert len(starts) == len(ids_k)
+                for j, st in enumerate(starts):
+                    en = starts[j + 1] if j + 1 < len(starts) else len(text)
+                    blk = [ln for ln in text[st:en] if ln != ""]
+                    # (the shard numbered its sentences 0..; the global number is restored when writing)
+                    blocks[int(ids_k[j])] = (j, blk)
+            with open(os.path.join(GOLD, "attack_%s_log.txt" % a.what), "w") as f:
+                f.write("\n".join(header) + "\n")
+                for pos, g in enumerate(everything):
+                    j, blk = blocks[g]
+                    blk = list(blk)
+                    blk[0] = blk[0].replace("Sentence Pair.%d*" % j, "Sentence Pair.%d*" % pos)
+                    f.write("\n".join(blk) + "\n")
+            print("merged %d sentences; reference time %.0f thread-seconds" % (len(everything), out["ref_seconds"]))
     elif a.what == "main":
         subset = list(range(a.n)) + list(range(500, 500 + a.n))
         run_attack(subset, dict(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2), ckpt, "notnll", a.threads)

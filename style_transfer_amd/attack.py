@@ -132,6 +132,17 @@ class LeanRecord:
     def cpu(self):
         return self.to("cpu")
 
+    def span(self, lo, hi, row_start=None):
+        """sentences [lo, hi) of this record (views); row_start [S+1]: prefix sums of the changed counts, computed
+        here when not given (pass it when cutting one record into many spans)"""
+        if row_start is None:
+            row_start = torch.zeros(len(self) + 1, dtype=torch.int64)
+            row_start[1:] = torch.cumsum(self.changed.sum(1, dtype=torch.int64).cpu(), 0)
+        cut = lambda t: None if t is None else t[lo:hi]
+        return LeanRecord(self.n_iter[lo:hi], self.init_ids[lo:hi], self.changed[lo:hi],
+                          self.rows[int(row_start[lo]):int(row_start[hi])], cut(self.like_ids), cut(self.unlike_ids),
+                          cut(self.final_latent))
+
     @staticmethod
     def cat(parts):
         cat = lambda xs: None if any(x is None for x in xs) else torch.cat(xs, 0)

@@ -222,7 +222,7 @@ class AttackSet:
         return cls(origin, like, unlike, labels)
 
     @classmethod
-    def synthetic(cls, n, vocab_size, shape="yelp", n_pos=10, n_neg=10, seed=1234, word_counts=None):
+    def synthetic(cls, n, vocab_size, shape="yelp", n_pos=10, n_neg=10, seed=1234, word_counts=None, origins_only=False):
         """SURVEY.md §8d synthetic sets: yelp-shaped origins 6-15 tokens (mean ~10.3), refs/sims 1-16;
         amazon-shaped origins 8-15, refs/sims 8-31; ids uniform in [4, V), or — when word_counts (the
         counts column of word_to_id.txt) is given — drawn from that unigram (Zipfian) distribution.
@@ -247,6 +247,8 @@ class AttackSet:
         else:
             draw = lambda k: rng.integers(4, vocab_size, k, dtype=np.int32)
         mk = lambda lens: Ragged.from_lengths(draw(int(lens.sum())), lens)
+        if origins_only:     # the same origins as the full set (they are drawn first), without the 20 references each
+            return cls(mk(olen), Ragged(np.zeros(0, np.int32), np.zeros(1, np.int64)), Ragged(np.zeros(0, np.int32), np.zeros(1, np.int64)), None, 0, 0)
         return cls(mk(olen), mk(plen), mk(nlen), None, n_pos, n_neg)
 
     def subset(self, idx):

@@ -55,6 +55,27 @@ def format_attack_block(vocab: VocabBytes, data, rec, first_index=0, eos=3, pad=
     return out
 
 
+def format_attack_blocks(vocab: VocabBytes, data, rec, first_index=0, threads=8, min_chunk=4096, **kw):
+    """format_attack_block over a large CPU record (rank 0 after the gather of a multi-GPU run): the sentence range is
+    cut into chunks formatted on `threads` host threads (st_format_attack_log is a C function: ctypes drops the GIL)
+    and yielded in order."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    S = len(data)
+    n = max(1, min(threads * 4, S // max(1, min_chunk)))
+    if n == 1:
+        yield format_attack_block(vocab, data, rec, first_index, **kw)
+        return
+    row_start = torch.zeros(S + 1, dtype=torch.int64)
+    row_start[1:] = torch.cumsum(rec.changed.sum(1, dtype=torch.int64), 0)
+    cuts = [S * i // n for i in range(n + 1)]
+    with ThreadPoolExecutor(threads) as ex:
+        futs = [ex.submit(format_attack_block, vocab, data.span(cuts[i], cuts[i + 1]), rec.span(cuts[i], cuts[i + 1], row_start),
+                          first_index + cuts[i], **kw) for i in range(n)]
+        for f in futs:
+            yield f.result()
+
+
 class LogWriter:
     """print_and_log: message to stdout (optional) and to the log file with the reference's prefix."""
 

@@ -369,7 +369,9 @@ def main(argv=None):
             mine = LeanRecord.cat(kept) if kept else LeanRecord.empty(cfg, data.n_pos, data.n_neg, device)
             full = gather_to_rank0(mine, rank, world, device)
             if rank == 0:
-                log.write_block(fmt(0, len(data), full.cpu()))
+                from .logfmt import format_attack_blocks
+                for block in format_attack_blocks(vocab, data, full.cpu(), 0, eos=args.id_eos, pad=args.id_pad, unk=args.id_unk):
+                    log.write_block(block)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -566,7 +566,7 @@ def test_bench_self_launches_two_ranks(tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2048", "--steps", "2",
-                          "--warmup", "1", "--no-side-runs"], env=env, capture_output=True, text=True, timeout=600)
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -574,3 +574,8 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert j["n_gpus"] == 2 and j["config"]["distinct_batches"] is True and j["config"]["sentences_per_step"] == 4096
     assert j["value"] > 0 and j["whole_step"]["executed_token_steps"] > 0 and "cpu_baseline" not in j
     assert abs(j["value"] - 4096 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    # what config 4 names: shards through the product pipeline on every rank + the gather of the records to rank 0 + the
+    # log written by rank 0 in global order, timed as one region
+    e = j["config"]["end_to_end_with_final_gather"]
+    assert e["end_to_end_sentences_per_s"] > 0 and e["gather_ms"] > 0 and e["log_write_ms"] > 0 and e["compute_ms"] > 0
+    assert e["end_to_end_sentences_per_s"] < j["value"] * 1.5

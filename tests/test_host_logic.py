@@ -418,3 +418,43 @@ def test_bench_self_launch_control_flow_without_a_gpu():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["dry_run"] is True and j["ms_per_step"] >= 20.0   # the slower rank's time
+
+
+def test_bench_launcher_returns_promptly_when_a_worker_dies():
+    """A worker that dies before the rendezvous must not leave its sibling (waiting in the store) and the launcher hanging:
+    the launcher polls its children, stops the others and passes the failing return code on."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ST_BENCH_TEST_DIE_RANK"] = "1"
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    dt = time.monotonic() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    assert "rank 1 exited with 3" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]      # no result line from a broken run
+    assert dt < 60, dt
+
+
+def test_parallel_log_formatter_equals_the_single_block(id_to_word):
+    """format_attack_blocks (rank 0 after the gather: chunks on host threads, in order) == format_attack_block"""
+    import torch
+    from style_transfer_amd.attack import LeanRecord
+    from style_transfer_amd.data import AttackSet
+    from style_transfer_amd.logfmt import VocabBytes, format_attack_block, format_attack_blocks
+    rng = np.random.default_rng(3)
+    S, I, T, V = 3000, 18, 59, len(id_to_word)
+    n_iter = rng.integers(1, I + 1, S).astype(np.int32)
+    changed = ((rng.random((S, I)) < 0.3) & (np.arange(I)[None, :] < n_iter[:, None])).astype(np.uint8)
+    mk = lambda n: np.where(rng.random((n, T)) < 0.1, 3, rng.integers(4, V, (n, T))).astype(np.int32)
+    rec = LeanRecord(torch.from_numpy(n_iter), torch.from_numpy(mk(S)), torch.from_numpy(changed), torch.from_numpy(mk(int(changed.sum()))))
+    full = AttackSet.synthetic(S, V, "yelp", seed=9)
+    only = AttackSet.synthetic(S, V, "yelp", seed=9, origins_only=True)
+    assert np.array_equal(full.origin_r.tokens, only.origin_r.tokens) and len(only) == S and only.n_pos == 0
+    vocab = VocabBytes(id_to_word)
+    one = format_attack_block(vocab, full, rec, 7).tobytes()
+    many = [b.tobytes() for b in format_attack_blocks(vocab, only, rec, 7, threads=4, min_chunk=100)]
+    assert len(many) > 4 and b"".join(many) == one
+    sub = rec.span(100, 250)
+    assert len(sub) == 150 and int(sub.changed.sum()) == sub.rows.shape[0]
+    assert format_attack_block(vocab, full.span(100, 250), sub, 107).tobytes() in one
