@@ -56,6 +56,10 @@ class AttackConfig:
     # change inside a round have the rest of that round's decodes discarded (44 % of yelp-shaped sentences run all
     # 18 iterations, the others stop anywhere from iteration 7 on)
     iters_per_decode: object = (12, 6)
+    # Small batches are latency-bound (a decode step costs the same for 300 rows as for 5000), so halving the number of
+    # decode steps beats not decoding iterations that may be discarded: up to this many sentences ALL iterations are
+    # decoded in one round (batch 256: 12.9 k -> 20.8 k sentences/s with this alone; results identical by construction)
+    single_round_max_batch: int = 8192
     defer_stragglers: bool = True  # see run_prepared: sentences whose decodes do not end are finished in an extra round
     count_units: bool = False
 
@@ -292,6 +296,8 @@ class AttackRunner:
             sched = [max(1, min(c.iters_per_decode, I))] * I
         else:
             sched = [max(1, int(v)) for v in c.iters_per_decode] + [1] * I
+            if B <= c.single_round_max_batch:
+                sched = [I]
         torch.cuda.synchronize(dev)
         tm["setup_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()

@@ -415,6 +415,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
                                 void* workspace, size_t workspace_bytes, int* n_steps_host, void* stream) {
   ST_TRY(check_weights(w, max_len));
   ST_CHECK_ARG(B >= 0, "B=%d", B);
+  rp_ab_env();
   if (n_steps_host) *n_steps_host = 0;
   if (B == 0) return ST_OK;
   ST_CHECK_ARG(latent && out_ids && workspace, "NULL buffer");

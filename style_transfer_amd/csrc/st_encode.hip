@@ -525,6 +525,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
   int32_t* first_sent = (int32_t*)base;
   ST_HIP(hipMemsetAsync(range_flag, 0, 2 * sizeof(int), st));
   const int R = n_rows;
+  rp_ab_env();
   // fused QKV + attention (f16x3, every sentence <= 16 tokens): ownership windows of 65 - max_sent_len >= 49 rows
   static const bool ab_unfused = getenv("ST_AB_ENC_UNFUSED") != nullptr;  // A/B: the two-kernel form
   const bool fused = w->gemm_format == ST_GEMM_F16X3 && max_sent_len <= 16 && max_sent_len >= 1 && !ab_unfused;

@@ -51,6 +51,11 @@ static int rp_screen_paired = 1;
 static int rp_argmax_shape16 = 1;
 static int rp_tail_persistent = 1;
 static int rp_tail_shape16 = 1;
+// Below this many live rows the unfused kernels (column splits) are used instead of the half-layer kernel.  Round 3: 64 (was
+// 4096).  With a few thousand rows the unfused chain (O-projection 15 us + FFN1 38 us + FFN2 63 us per layer at 3328 rows)
+// is latency-bound on every workgroup streaming a whole weight matrix; one panel per CU through the half-layer kernel takes
+// ~45 us whatever the row count (batch-256 regime 12.9 k -> 18.3 k sentences/s, gpurun_out/small_sweep.txt).
+static int rp_tail_min_rows = 64;
 static inline void rp_ab_env() {
   static bool done = false;
   if (done) return;
@@ -61,6 +66,7 @@ static inline void rp_ab_env() {
   if (getenv("ST_AB_SCREEN32")) rp_screen_shape16 = 0;
   if (getenv("ST_AB_SCREEN_UNPAIRED")) rp_screen_paired = 0;
   if (getenv("ST_AB_ARGMAX32")) rp_argmax_shape16 = 0;
+  if (getenv("ST_AB_TAIL_MIN_ROWS")) rp_tail_min_rows = atoi(getenv("ST_AB_TAIL_MIN_ROWS"));
 }
 
 
@@ -2126,7 +2132,7 @@ static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
 // HBM traffic per row: att + x in, x out (3 KiB) instead of 13 KiB for the unfused chain.
 // ------------------------------------------------------------------------------------------------
 #define RP_TAIL_LDS ((2 * 64 * ST_LDA + 64) * 4)  /* two panels + the cross-attention index of the next panel's rows */
-#define RP_TAIL_MIN_ROWS 4096  /* below this the unfused kernels (column splits) fill the chip better */
+#define RP_TAIL_MIN_ROWS rp_tail_min_rows
 #define RP_TAIL_MMA6(ACC0, ACC1, A0H, A0L, A1H, A1L, BH, BL) \
   ACC0 = mfma16h(A0H, BH, ACC0);                             \
   ACC1 = mfma16h(A1H, BH, ACC1);                             \
