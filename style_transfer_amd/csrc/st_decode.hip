@@ -232,6 +232,214 @@ __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Decode QKV projection AND the single-query self-attention of one layer in one kernel (f16x3 format, pos < 16).
+// Phase 1 is rp_lin16_kernel<EPI_QKV> without a column split: a workgroup owns a 64-row panel and all 24 column
+// blocks; wave w takes its blocks in the order k, k, v, v, q, q.  k and v go to the K/V cache from the accumulators
+// (the stores of block i - 1 inside the MFMAs of block i); the two q blocks stay in accumulators until every wave has
+// finished reading the panel, then they are written over it in LDS as f32 rows: q never goes to HBM.
+// Phase 2 is attn_step16_kernel<true>, one wave per row and 16 rows per wave, q from LDS, K / V rows 0 .. pos from the
+// cache (row pos was written in phase 1 by this workgroup: __threadfence + barrier; its lines were never read before
+// by this CU, so the L1 holds no stale copy).  Rows are taken RIF at a time so that the loads of several rows are in
+// flight together.  Every value is computed by the same instruction sequence as in the two-kernel form: identical
+// results.  Two workgroups share a CU (66.8 KiB of LDS each): one's K / V stream runs under the other's MFMAs, which
+// is the point - the two kernels it replaces ran at HBM time PLUS MFMA time.
+// ------------------------------------------------------------------------------------------------
+template <int NK>
+__global__ __launch_bounds__(256, 2) void dec_qkv_attn16_kernel(GemmArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;  // [64][ST_LDA]
+  int* slot = (int*)(smem + 64 * ST_LDA);
+  const int n = a.n_dev ? *a.n_dev : a.n_host;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int pos = a.pos;
+  int bad = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int f = tid + i * 256;
+    const int r = f >> 6, c4 = f & 63;
+    *(f32x4*)(As + r * ST_LDA + c4 * 4) = *(const f32x4*)(a.X + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+  }
+  if (tid < 64) slot[tid] = a.idx[min(m0 + tid, n - 1)];
+  __syncthreads();
+  {
+    const f32x4 ga = *(const f32x4*)(a.ln_a + lane * 4);
+    const f32x4 gb = *(const f32x4*)(a.ln_b + lane * 4);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      float* row = As + (wave * 16 + rr) * ST_LDA;  // one wave owns the whole row: in-place is safe
+      panel_store4_nb16(row, lane, layernorm256r(*(f32x4*)(row + lane * 4), ga, gb), bad);
+    }
+  }
+  __syncthreads();
+
+  // this wave's six 32-column blocks: k (8 + w, 12 + w), v (16 + w, 20 + w), q (w, 4 + w)
+  auto blk_of = [&](int i) -> int { i = min(i, 5); return wave + 4 * (i < 4 ? i + 2 : i - 4); };
+  const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, 24 * 32768, 0x00020000);
+  const float* Ab = As + r16 * ST_LDA + rp16_frag_pos(0, g);
+  auto wbase = [&](int i) -> int { return blk_of(i) * 32768; };
+  auto wfetch = [&](int p, int d, f32x4 (&dst)[4]) {
+    dst[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl, p + d * 4096, 0));
+    dst[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1024, p + d * 4096, 0));
+    dst[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 256, p + d * 4096, 0));
+    dst[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1280, p + d * 4096, 0));
+  };
+  size_t kvrow[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) kvrow[rt] = (size_t)((long)slot[16 * rt + r16] * a.kv_stride) + (size_t)pos * 256 + 4 * g;
+  const bool full = m0 + 64 <= n;
+  auto put = [&](const f32x4& v, int i, int ft, int rt) {  // k / v blocks only (i < 4)
+    const int blk = blk_of(i);
+    if (!full && m0 + 16 * rt + r16 >= n) return;
+    float* base = (blk < 16) ? a.kbase : a.vbase;
+    *(f32x4*)(base + (((blk << 5) + 16 * ft) & 255) + kvrow[rt]) = v;
+  };
+  f32x4 rw[RP_LIN_RING][4];
+#pragma unroll
+  for (int j = 0; j < RP_LIN_RING; ++j) wfetch(wbase(0), j, rw[j]);
+  f32x4 pn[4];
+  pn[0] = *(const f32x4*)(Ab);
+  pn[1] = *(const f32x4*)(Ab + 128);
+  pn[2] = *(const f32x4*)(Ab + 16 * ST_LDA);
+  pn[3] = *(const f32x4*)(Ab + 16 * ST_LDA + 128);
+  auto block = [&](f32x4 (&acc)[2][4], int i, const f32x4 (&o)[2][4], int io, bool do_put) {
+    const int Wb = wbase(i);
+    const int Wn = wbase(i + 1);
+    {
+      const int col = (blk_of(i) << 5) + 4 * g;
+      const f32x4 bv0 = *(const f32x4*)(a.bias + col), bv1 = *(const f32x4*)(a.bias + col + 16);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[0][rt] = bv0;
+        acc[1][rt] = bv1;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int sl = d % RP_LIN_RING;
+      const h8 wh0 = as_h8(rw[sl][0]), wl0 = as_h8(rw[sl][1]), wh1 = as_h8(rw[sl][2]), wl1 = as_h8(rw[sl][3]);
+      if (d + RP_LIN_RING < 8)
+        wfetch(Wb, d + RP_LIN_RING, rw[sl]);
+      else
+        wfetch(Wn, d + RP_LIN_RING - 8, rw[sl]);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+        {
+          const int nd = hf ? ((d + 1) & 7) : d, nrt = hf ? 0 : 2;
+          const float* q = Ab + nrt * 16 * ST_LDA + 8 * nd;
+          pn[0] = *(const f32x4*)(q);
+          pn[1] = *(const f32x4*)(q + 128);
+          pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+          pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+        }
+        const int rt = 2 * hf;
+        acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
+        if (do_put && hf == 1) put(o[d & 1][d >> 1], io, d & 1, d >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  f32x4 A[2][4], B[2][4];
+  block(A, 0, A, 0, false);
+  block(B, 1, A, 0, true);
+  block(A, 2, B, 1, true);
+  block(B, 3, A, 2, true);
+  block(A, 4, B, 3, true);   // A: q block `wave`
+  block(B, 5, B, 5, false);  // B: q block `wave + 4`
+  if (bad && a.range_flag) *a.range_flag = 1;
+  __syncthreads();  // every wave has read its last panel fragment: the panel becomes the q tile (f32 rows)
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      float* qrow = As + (16 * rt + r16) * ST_LDA + 16 * ft + 4 * g;
+      *(f32x4*)(qrow + 32 * wave) = A[ft][rt];
+      *(f32x4*)(qrow + 32 * (wave + 4)) = B[ft][rt];
+    }
+  __threadfence();  // this workgroup's new K / V rows are read back below
+  __syncthreads();
+
+  // ---- phase 2: attention, one wave per row ----
+  constexpr int RIF = NK <= 4 ? 4 : (NK <= 8 ? 2 : 1);
+  for (int r0 = 0; r0 < 16; r0 += RIF) {
+    f32x4 kr[RIF][NK], vr[RIF][NK];
+#pragma unroll
+    for (int u = 0; u < RIF; ++u) {
+      const int row = wave * 16 + r0 + u;
+      const long s = slot[min(row, 63)];
+      const float* K = a.kbase + s * a.kv_stride + lane * 4;
+      const float* V = a.vbase + s * a.kv_stride + lane * 4;
+#pragma unroll
+      for (int j = 0; j < NK; ++j)
+        if (j <= pos) {  // uniform
+          kr[u][j] = *(const f32x4*)(K + (size_t)j * 256);
+          vr[u][j] = *(const f32x4*)(V + (size_t)j * 256);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RIF; ++u) {
+      const int row = wave * 16 + r0 + u;
+      if (m0 + row >= n) continue;  // uniform
+      const f32x4 qv = *(const f32x4*)(As + row * ST_LDA + lane * 4);
+      float sc[NK];
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        sc[j] = -INFINITY;
+        if (j <= pos) {
+          const float part = fmaf(qv.x, kr[u][j].x, fmaf(qv.y, kr[u][j].y, fmaf(qv.z, kr[u][j].z, qv.w * kr[u][j].w)));
+          sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
+          m = fmaxf(m, sc[j]);
+        }
+      }
+      float sum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NK; ++j)
+        if (j <= pos) {
+          sc[j] = __expf(sc[j] - m);
+          sum += sc[j];
+        }
+      const float inv = 1.0f / sum;
+      f32x4 o4 = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < NK; ++j)
+        if (j <= pos) o4 += (sc[j] * inv) * vr[u][j];
+      *(f32x4*)(a.out + (size_t)(m0 + row) * 256 + lane * 4) = o4;
+    }
+  }
+}
+
+template <int NK>
+static int launch_dec_qkv_attn16_t(const GemmArgs& a, int n_bound, hipStream_t st) {
+  ST_ENSURE_LDS((dec_qkv_attn16_kernel<NK>), RP_LDS);
+  hipLaunchKernelGGL((dec_qkv_attn16_kernel<NK>), dim3((n_bound + 63) / 64), dim3(256), RP_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+static int launch_dec_qkv_attn16(const GemmArgs& a, int n_bound, hipStream_t st) {
+  if (n_bound <= 0) return ST_OK;
+  if (a.pos < 4) return launch_dec_qkv_attn16_t<4>(a, n_bound, st);
+  if (a.pos < 8) return launch_dec_qkv_attn16_t<8>(a, n_bound, st);
+  return launch_dec_qkv_attn16_t<16>(a, n_bound, st);
+}
+
+// ------------------------------------------------------------------------------------------------
 // merge the generator's per-split (best, index, second) partials; emit the token; keep the sentence
 // live unless it produced EOS/PAD (early exit) or this was the last step.
 //   rows != null: partial row i belongs to live row rows[i] (the redo pass over ambiguous rows).
@@ -457,6 +665,13 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   const float margin_c = 2.0f * 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f) * w->gen_w_maxnorm;
   // padded generator bias / column norms: the 16x16x32 generator kernels (screening pass, exact argmax) load them 4 at a time
   if (w->gemm_format == ST_GEMM_F16X3) ST_TRY(launch_rp_screen_colpad(w->gen_b, w->gen_w_norm, w->vocab, ws.colpad, st));
+  // One kernel for a layer's QKV projection + attention (f16x3, pos < 16): MEASURED NEGATIVE, off unless ST_AB_DEC_FUSED is
+  // set (same-box A/B, profiles/r03_dec_fused_negative.txt: identical results, 130 k against 145 k sentences/s).  Its
+  // attention phase has 8 waves x 1-4 rows in flight per CU and each wave walks its 16 rows in sequential HBM round trips;
+  // attn_step16_kernel keeps 12 independent rows per CU in flight all the time.
+  static const bool ab_fused = getenv("ST_AB_DEC_FUSED") != nullptr;
+  static const int fuse_min_rows = getenv("ST_AB_DEC_FUSE_MIN_ROWS") ? atoi(getenv("ST_AB_DEC_FUSE_MIN_ROWS")) : 1;
+  const bool fuse_qkv_attn = w->gemm_format == ST_GEMM_F16X3 && ab_fused && kv_stride % 4 == 0 && ((size_t)ws.kv & 15) == 0;
   int n_bound = B;
   int cur = 0;
   int steps = 0;
@@ -479,6 +694,10 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
       g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
       const int qsplits = rp_splits(n_bound, 768, n_bound <= 2048 ? 8 : 3, rp_nw(w->gemm_format, 8));
+      if (fuse_qkv_attn && pos < 16 && n_bound >= fuse_min_rows) {
+        g.kbase = kb; g.vbase = vb; g.pos = pos; g.out = ws.att;   // (bases without the pos offset)
+        ST_TRY(launch_dec_qkv_attn16(g, n_bound, st));
+      } else {
       if (w->gemm_format == ST_GEMM_F16X3)
         ST_TRY(launch_rp_lin_pipelined<EPI_QKV>(g, n_bound, qsplits, st));  // stores of block i-1 inside the MFMAs of block i
       else
@@ -493,6 +712,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
                            ws.att);
       ST_LAUNCH_CHECK();
+      }
       OFArgs of = {};
       of.fmt = w->gemm_format; of.range_flag = ws.cnt + 3;
       of.att = ws.att; of.n_dev = n_dev; of.n_host = n_bound; of.wo = y.wo; of.bo = y.bo; of.x = ws.x;

@@ -576,7 +576,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     if (w->gemm_format == ST_GEMM_F16X3 && R >= RP_TAIL_MIN_ROWS) {
       ProfPair pt;
       if (g_prof_on == ST_PROF_HALF_LAYER) ST_TRY(prof_begin(&pt, 2.0 * 256.0 * (256.0 + 2.0 * (double)w->d_ff), nullptr, R, st));
-      ST_TRY(launch_layer_tail(of, R, st));  // O-projection + FFN in one kernel
+      ST_TRY(launch_layer_tail<1>(of, R, st));  // O-projection + FFN in one kernel
       if (g_prof_on == ST_PROF_HALF_LAYER) ST_TRY(prof_end(&pt, st));
       continue;
     }

@@ -48,6 +48,7 @@ struct GemmArgs {
   //  DS : out[row*ldo + col] = g[row] * (exp(s - lse[row]) - [col == target]) * scale;  g == null: the bare exp(..) - [..]
   //  DST: the transposed block (rows = keys, columns = queries): out[row*ldo + col] = exp(s - lse[col]) - [row == row_offset + col]
   float scale;
+  int pos;             // dec_qkv_attn16_kernel: the decode step (keys 0 .. pos are attended; kbase / vbase are the layer's bases)
   int row_offset;
   const float* lse;
   const float* g;

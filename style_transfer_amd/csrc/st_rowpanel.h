@@ -2734,7 +2734,9 @@ static int launch_layer_tail32(const OFArgs& a, int n_bound, hipStream_t st) {
 // W fragment of k-steps (2d, 2d+1), feature tile ft, lane (r16, g): k = 32d + 8g .. +7 lives in the packed image at
 // k-step 2d + (g >> 1), lane 16 ft + r16 + 32 (g & 1): four 256-byte runs per wave load.
 // ------------------------------------------------------------------------------------------------
-template <int UNUSED = 0>
+// SITE only names the instantiation (0 = decoder, i.e. the edit loop; 1 = encoder, i.e. set-up), so that profiles and
+// counter passes can tell the two apart (tools/summarize_pmc.py): the code is the same.
+template <int SITE = 0>
 __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* P1 = smem;
@@ -3023,8 +3025,9 @@ static int launch_layer_tail64(const OFArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
+template <int SITE = 0>
 static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
-  ST_ENSURE_LDS((rp_layer_tail16_kernel<0>), RP_TAIL_LDS);
+  ST_ENSURE_LDS((rp_layer_tail16_kernel<SITE>), RP_TAIL_LDS);
   if (n_bound <= 0) return ST_OK;
   if (a.fmt != ST_GEMM_F16X3 || a.d_ff % 256 != 0 || !a.w2 || !a.b2) {
     st_set_error("rp_layer_tail16: needs the f16x3 format, d_ff %% 256 == 0 and w2/b2 (fmt=%d d_ff=%d)", a.fmt, a.d_ff);
@@ -3032,7 +3035,7 @@ static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
   }
   int grid = (n_bound + 63) / 64;
   if (rp_tail_persistent) grid = std::min(grid, st_cu_count());
-  hipLaunchKernelGGL(rp_layer_tail16_kernel<0>, dim3(grid), dim3(512), RP_TAIL_LDS, st, a);
+  hipLaunchKernelGGL(rp_layer_tail16_kernel<SITE>, dim3(grid), dim3(512), RP_TAIL_LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
@@ -3041,9 +3044,10 @@ static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
 // and 229376 rows, bit-identical outputs; profiles/r02_kbench_tail_ab.txt): it hides the panel load, LayerNorm, store and
 // turnaround phases as intended, but every W fragment feeds three MFMAs instead of six and the doubled L2 -> CU weight
 // stream costs more than the overlap gains.  launch_layer_tail32 stays reachable from tools/kbench.cpp only.
+template <int SITE = 0>
 static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) {
   rp_ab_env();
-  return rp_tail_shape16 ? launch_layer_tail16(a, n_bound, st) : launch_layer_tail64(a, n_bound, st);
+  return rp_tail_shape16 ? launch_layer_tail16<SITE>(a, n_bound, st) : launch_layer_tail64(a, n_bound, st);
 }
 
 // packed-weight helpers -------------------------------------------------------------------------

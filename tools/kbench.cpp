@@ -405,7 +405,7 @@ int main(int argc, char** argv) {
       // A/B: 16x16x32 tiles vs 32x32x16 tiles (both persistent); outputs compared by value (the MFMA-internal summation order differs)
       double t16 = 0, t32x = 0;
       for (int rep = 0; rep < 3; ++rep) {
-        t16 += timeit([&] { launch_layer_tail16(a, n, st); }, 5);
+        t16 += timeit([&] { launch_layer_tail16<0>(a, n, st); }, 5);
         t32x += timeit([&] { launch_layer_tail64(a, n, st); }, 5);
       }
       printf("layer tail A/B n=%d: 16x16x32 tiles %8.1f us   32x32x16 tiles %8.1f us  (%.3f)\n", n, t16 / 3 * 1e6, t32x / 3 * 1e6, t16 / t32x);
@@ -414,7 +414,7 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(x0.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
       OFArgs b = a;
       b.x = xs;
-      launch_layer_tail16(b, n, st);
+      launch_layer_tail16<0>(b, n, st);
       CK(hipMemcpy(ya.data(), xs, x0.size() * 4, hipMemcpyDeviceToHost));
       CK(hipMemcpy(xs, x0.data(), x0.size() * 4, hipMemcpyHostToDevice));
       launch_layer_tail64(b, n, st);
@@ -460,7 +460,7 @@ int main(int argc, char** argv) {
 #ifdef ST_TAIL_STAMPS
     rp_tail_persistent = getenv("KBENCH_ONE_PANEL") ? 0 : 1;
     rp_tail_shape16 = getenv("KBENCH_SHAPE32") ? 0 : 1;
-    launch_layer_tail(a, n, st);
+    launch_layer_tail<0>(a, n, st);
     CK(hipDeviceSynchronize());
     rp_tail_persistent = 1;
     unsigned long long hs[64];
