@@ -92,6 +92,7 @@ def parse_args(argv=None):
                     help="skip the short extra runs reported in config (exact-f32 format, fixed 59 steps, log decodes on, end to end)")
     ap.add_argument("--gemm-format", default="f16x3", choices=["f16x3", "f32"],
                     help="operand format of the AE weight GEMMs: 3-product f16 split (f32-grade results) or exact f32 MFMA")
+    ap.add_argument("--scorer-format", default=None, choices=["f16x3", "f32"], help="operand format of the style scorer (default: --gemm-format)")
     ap.add_argument("--config", default="attack", choices=["attack", "simloss"],
                     help="attack: the headline workload (BASELINE configs 1-4); simloss: BASELINE config 5, one contrastive constraint-loss "
                          "step (11 views, forward + backward) with B = --simloss-batch GLOBAL in-batch negatives, rows sharded over the GPUs")
@@ -339,7 +340,8 @@ def main(argv=None):
     ae_file = os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)
     ae = W.AEWeights(W.load_state_dict_file(ae_file), dev, gemm_format=a.gemm_format)
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
-                             W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
+                             W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev,
+                             gemm_format=a.scorer_format or a.gemm_format)
     ipd = int(a.iters_per_decode) if "," not in a.iters_per_decode else tuple(int(v) for v in a.iters_per_decode.split(","))
     cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=a.log_decodes, early_exit=not a.fixed_steps,
                        iters_per_decode=ipd)
@@ -430,7 +432,9 @@ def main(argv=None):
         # (1) exact-f32 operand format, same batches
         fresh()
         ae32 = W.AEWeights(W.load_state_dict_file(ae_file), dev, gemm_format="f32")
-        r32 = AttackRunner(ae32, scorer, cfg, dev)
+        sc32 = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
+                               W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev, gemm_format="f32")
+        r32 = AttackRunner(ae32, sc32, cfg, dev)
         side["exact_f32_format_sentences_per_s"] = timed(r32, preps[:2])
         r32.ws.buf = None
         del r32, ae32

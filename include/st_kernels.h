@@ -92,6 +92,11 @@ typedef struct StScorerWeights {
   const float *s3_w, *s3_wt, *s3_b;   /* 512 -> 256                              */
   const float *p1_w, *p1_wt, *p1_b;   /* 256 -> 128 (100 padded; +BN folded), LeakyReLU(0.2) */
   const float *p2_w, *p2_wt, *p2_b;   /* 128 -> 256                              */
+  int32_t gemm_format;                /* ST_GEMM_F32: exact f32 MFMA.  ST_GEMM_F16X3: every `w` / `wt` image is packed in the
+                                         f16x3 format from the matrix MULTIPLIED by a power of two (one per layer, chosen so
+                                         that max |W| lies in [2^13, 2^14): BatchNorm-folded weights are small, and an f16
+                                         lo part needs magnitude); the kernels multiply the products by unscale[]        */
+  float unscale[5];                   /* f16x3: 1 / (that power of two) for s1, s2, s3, p1, p2 (exact)                  */
 } StScorerWeights;
 
 /* z = SiameseNet(x) for n rows (replaces batch_forward(1, siamese_net, like/unlike_latent),
@@ -99,6 +104,12 @@ typedef struct StScorerWeights {
  * loop-invariant).  If unit != 0 each row is divided by max(||z||, 1e-8) (F.cosine_similarity's
  * normalisation) so the edit step can use dot products.                                          */
 int st_scorer_embed(const StScorerWeights* w, const float* x, float* z, int n, int unit, void* stream);
+
+/* The f16x3 scorer kernels raise a sticky per-process flag on the device when a value leaves the f16 range (|x| >= 65504
+ * or NaN: the split products would then return garbage).  Reading it synchronises the device, so it is not done per step:
+ * call this once after a batch of steps; out_of_range != 0 means the results since the last reset are invalid (use
+ * ST_GEMM_F32).  No counterpart in the reference.                                                                        */
+int st_scorer_status(int* out_of_range, int reset);
 
 /* flags for st_scorer_edit_step */
 #define ST_F_NOT_NLL 1        /* --not_nll       (siamese_contrastive.py:424-436) */

@@ -305,6 +305,11 @@ if __name__ == "__main__":
         sub = [0, 1, 500, 501]
         for name, lr in (("SGD", 200.0), ("AdamW", 0.2), ("Adamax", 0.2), ("RMSprop", 0.05), ("Adagrad", 0.5)):
             run_attack(sub, dict(not_nll=True, victim_optimizer=name, pos_victim_lr=lr, neg_victim_lr=lr), ckpt, "opt_" + name.lower(), a.threads)
+    elif a.what == "optimizers2":
+        # the remaining first-order torch.optim rules (NAdam, RAdam, Adadelta, ASGD, Rprop), torch defaults apart from lr
+        sub = [0, 1, 500, 501]
+        for name, lr in (("NAdam", 0.2), ("RAdam", 0.2), ("Adadelta", 50.0), ("ASGD", 200.0), ("Rprop", 0.05)):
+            run_attack(sub, dict(not_nll=True, victim_optimizer=name, pos_victim_lr=lr, neg_victim_lr=lr), ckpt, "opt_" + name.lower(), a.threads)
     elif a.what == "variants":
         sub = [0, 1, 2, 500, 501, 502]
         if not os.path.exists(os.path.join(GOLD, "attack_nll.npz")):

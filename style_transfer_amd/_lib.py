@@ -18,7 +18,7 @@ ST_DEC_NO_SCREEN = 2
 ST_PROF_OFF, ST_PROF_GENERATOR, ST_PROF_HALF_LAYER = 0, 1, 2
 ST_GEMM_F32, ST_GEMM_F16X3 = 0, 1
 GEMM_FORMATS = {"f32": ST_GEMM_F32, "f16x3": ST_GEMM_F16X3}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -26,7 +26,7 @@ fp = C.c_void_p  # device pointers travel as integers
 class StScorerWeights(C.Structure):
     _fields_ = [(n, fp) for n in (
         "s1_w", "s1_wt", "s1_b", "s2_w", "s2_wt", "s2_b", "s3_w", "s3_wt", "s3_b",
-        "p1_w", "p1_wt", "p1_b", "p2_w", "p2_wt", "p2_b")]
+        "p1_w", "p1_wt", "p1_b", "p2_w", "p2_wt", "p2_b")] + [("gemm_format", C.c_int32), ("unscale", C.c_float * 5)]
 
 
 class StDecLayer(C.Structure):
@@ -84,6 +84,7 @@ EXPORTS = {
     "st_work_counters_read": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "st_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "st_pack_weight": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp]),
+    "st_scorer_status": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
     "st_scorer_edit_step": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                       C.c_int, C.c_float, C.c_int, fp, fp, fp, fp]),

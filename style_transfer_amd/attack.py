@@ -400,6 +400,8 @@ class AttackRunner:
         if not c.count_units:
             n_units = int(was_active.sum().item())
         torch.cuda.synchronize(dev)
+        if self.scorer is not None and self.scorer.gemm_format == "f16x3":
+            self.scorer.check_range()
         tm["loop_s"] = time.perf_counter() - t1
         tm["units"] = n_units
         res.timing = tm

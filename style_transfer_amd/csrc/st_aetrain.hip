@@ -704,6 +704,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
                p->n_layers, p->d_ff, p->vocab);
   ST_CHECK_ARG(B >= 1 && n_enc_sent >= 2 * B && n_enc_sent % B == 0, "n_enc_sent=%d must be (1 + views) * B with views >= 1 (B=%d)",
                n_enc_sent, B);
+  ST_CHECK_ARG(B % 32 == 0, "st_ae_train_step: the similarity block's backward needs B %% 32 == 0 (B=%d)", B);
   ST_CHECK_ARG(n_enc_rows > 0 && n_dec_rows > 0, "empty batch");
   ST_CHECK_ARG(enc_tokens && enc_pos && enc_off && dec_tokens && dec_pos && dec_targets && dec_off && losses_out && workspace,
                "NULL buffer");
@@ -815,14 +816,9 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     const float* like = w.lat + (size_t)(1 + v) * B * 256;
     float* dlike = w.dlat + (size_t)(1 + v) * B * 256;
     ST_TRY(st_simloss_fwd(w.lat, like, B, B, tau, 0, w.con_rows + (size_t)v * B, w.sl_lse, w.sl_scratch, w.sl_scratch_bytes, c.st));
-    if (B % 32 == 0) {
-      ST_TRY(st_simloss_bwd(w.lat, like, B, B, tau, 0, w.sl_lse, w.sl_g, w.sl_dori, dlike, w.sl_scratch, w.sl_scratch_bytes, c.st));
-      hipLaunchKernelGGL(ae_add_kernel, ELEMS((long)B * 256), w.dlat, w.sl_dori, (long)B * 256);
-      ST_LAUNCH_CHECK();
-    } else {
-      st_set_error("st_ae_train_step: the similarity block's backward needs B %% 32 == 0 (B=%d)", B);
-      return ST_EINVAL;
-    }
+    ST_TRY(st_simloss_bwd(w.lat, like, B, B, tau, 0, w.sl_lse, w.sl_g, w.sl_dori, dlike, w.sl_scratch, w.sl_scratch_bytes, c.st));
+    hipLaunchKernelGGL(ae_add_kernel, ELEMS((long)B * 256), w.dlat, w.sl_dori, (long)B * 256);
+    ST_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(ae_sum_kernel, dim3(1), dim3(256), 0, c.st, w.con_rows, n_views * B, 1.0f / ((float)B * (float)n_views), losses_out + 1);
   ST_LAUNCH_CHECK();

@@ -104,3 +104,6 @@ __device__ __forceinline__ f32x16 mfma16h(h8 a, h8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ h8 as_h8(f32x4 v) { return __builtin_bit_cast(h8, v); }
+// D(16 x 16) += A(16 x 32) . B(32 x 16) on f16: lane l holds A[row l & 15][k = 8 (l >> 4) .. +7], B[k = same][col l & 15];
+// D: col = l & 15, rows 4 (l >> 4) .. +3 in the four registers
+__device__ __forceinline__ f32x4 mfma16x32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }

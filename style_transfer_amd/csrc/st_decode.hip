@@ -2,6 +2,7 @@
 // EncoderDecoder.greedy_decode, /root/reference/method/yelp/model.py:271-299, which re-runs the whole
 // decoder over the growing prefix at every step) + generator GEMM with fused argmax (model.py:200-207,
 // :290-292).  One launch sequence per decode step over the COMPACTED list of live sentences.
+#define ST_RP_DEFINE_SWITCHES  /* this translation unit owns the kernel-form switches of st_rowpanel.h */
 #include "st_rowpanel.h"
 
 #include <stdarg.h>
@@ -15,7 +16,7 @@ void st_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 5; }
+extern "C" int st_abi_version(void) { return 6; }
 
 // ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
 #include <vector>
@@ -669,9 +670,8 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   // set (same-box A/B, profiles/r03_dec_fused_negative.txt: identical results, 130 k against 145 k sentences/s).  Its
   // attention phase has 8 waves x 1-4 rows in flight per CU and each wave walks its 16 rows in sequential HBM round trips;
   // attn_step16_kernel keeps 12 independent rows per CU in flight all the time.
-  static const bool ab_fused = getenv("ST_AB_DEC_FUSED") != nullptr;
-  static const int fuse_min_rows = getenv("ST_AB_DEC_FUSE_MIN_ROWS") ? atoi(getenv("ST_AB_DEC_FUSE_MIN_ROWS")) : 1;
-  const bool fuse_qkv_attn = w->gemm_format == ST_GEMM_F16X3 && ab_fused && kv_stride % 4 == 0 && ((size_t)ws.kv & 15) == 0;
+  const bool fuse_qkv_attn = w->gemm_format == ST_GEMM_F16X3 && rp_dec_fused && kv_stride % 4 == 0 && ((size_t)ws.kv & 15) == 0;
+  const int fuse_min_rows = 1;
   int n_bound = B;
   int cur = 0;
   int steps = 0;
@@ -773,10 +773,8 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     if (screen) {
       // pass 1: one-product logits for every live row; rows with a clear winner are finished
       // per-column bound (gen_w_norm): the screening kernel books upper bounds, finish_kernel uses the winner's own norm
-      rp_ab_env();
       const float cx_c = 1.25f * (1.0f / 1024.0f + 1.0f / 65536.0f);
-      static const bool ab_maxnorm = getenv("ST_AB_SCREEN_MAXNORM") != nullptr;  // A/B: the one-bound-for-all-columns margin
-      const float* wnorm = (rp_screen_shape16 && w->gen_w_norm && !ab_maxnorm) ? w->gen_w_norm : nullptr;
+      const float* wnorm = (rp_screen_shape16 && w->gen_w_norm && !rp_screen_maxnorm) ? w->gen_w_norm : nullptr;
       gg.wnorm = wnorm; gg.scale = cx_c;
       ST_TRY(launch_rp_screen_pipelined(gg, n_bound, gsplits, st));  // bookkeeping interleaved with the next block's MFMAs
       gg.wnorm = nullptr;

@@ -31,10 +31,11 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
 // shuffles per query) ran the amazon shape at 1.43 ms per launch; this one is bound by the qkv row traffic.
 template <bool FAST>  // as in enc_attn16_kernel below
 __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
-                                                       float* __restrict__ out) {
+                                                       int n_rows, float* __restrict__ out) {
   const int s = blockIdx.x;
   const int r0 = off[s], len = off[s + 1] - r0;
   if (len <= 16 || len > 64) return;  // short sentences: enc_attn16_kernel
+  if (r0 < 0 || r0 + len > n_rows) return;  // bad offsets (flagged by enc_check_len_kernel): touch nothing
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const float* base = qkv + (size_t)r0 * 768 + h * 64;
@@ -117,12 +118,13 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
 // the exact-f32 format keeps expf.
 template <bool FAST>
 __global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
-                                                         int n_sent, float* __restrict__ out) {
+                                                         int n_sent, int n_rows, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n_sent) return;
   const int r0 = off[s], len = off[s + 1] - r0;
   if (len <= 0 || len > 16) return;
+  if (r0 < 0 || r0 + len > n_rows) return;  // bad offsets (flagged by enc_check_len_kernel): touch nothing
   const float* base = qkv + (size_t)r0 * 768 + lane * 4;
   f32x4 kr[16], vr[16];
 #pragma unroll
@@ -185,8 +187,10 @@ __global__ __launch_bounds__(256) void enc_window_kernel(const int32_t* __restri
                                                          int32_t* __restrict__ first_sent) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s > n_sent) return;
-  const int wa = s < n_sent ? min(off[s] / win, n_win) : n_win;        // window of this sentence's first row (sentinel: n_win)
-  const int wb = s > 0 ? min(off[s - 1] / win, n_win) : -1;            // window of the previous sentence's first row
+  // (offsets are the caller's and enc_check_len_kernel's verdict is read only at the end of the call: clamp, so that a
+  // negative or non-monotonic offset can never index first_sent[] out of range)
+  const int wa = s < n_sent ? min(max(off[s], 0) / win, n_win) : n_win;        // window of this sentence's first row (sentinel: n_win)
+  const int wb = s > 0 ? min(max(off[s - 1], 0) / win, n_win) : -1;            // window of the previous sentence's first row
   for (int w = wb + 1; w <= wa; ++w) first_sent[w] = s;                // windows (wb, wa] start with sentence s
 }
 
@@ -235,7 +239,8 @@ __global__ __launch_bounds__(512) void enc_qkv_attn16_kernel(EqaArgs a) {
       if (w.s_lo < w.s_hi) {
         w.r0 = a.off[w.s_lo];
         w.nr = a.off[w.s_hi] - w.r0;
-        if (w.nr < 0 || w.nr > 64) w.nr = 0;  // (enc_check_len_kernel has flagged longer sentences)
+        // (enc_check_len_kernel flags bad offsets; until the host reads that flag nothing may be touched through them)
+        if (w.nr < 0 || w.nr > 64 || w.r0 < 0 || w.r0 + w.nr > a.R || w.s_lo < 0 || w.s_hi > a.n_sent) w.nr = 0;
       }
     }
     return w;
@@ -456,14 +461,15 @@ __global__ __launch_bounds__(512) void enc_qkv_attn16_kernel(EqaArgs a) {
 
 // latent[s] = sum over the sentence's rows of sigmoid(LayerNorm_f(x[row]))   (model.py:236-240)
 __global__ __launch_bounds__(256) void enc_latent_kernel(const float* __restrict__ x, const int32_t* __restrict__ off,
-                                                         int n_sent, const float* __restrict__ ln_a,
+                                                         int n_sent, int n_rows, const float* __restrict__ ln_a,
                                                          const float* __restrict__ ln_b, float* __restrict__ latent) {
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n_sent) return;
   const int lane = threadIdx.x & 63;
   const f32x4 ga = *(const f32x4*)(ln_a + lane * 4), gb = *(const f32x4*)(ln_b + lane * 4);
   f32x4 acc = {0, 0, 0, 0};
-  for (int r = off[s]; r < off[s + 1]; ++r) {
+  const int r_lo = max(off[s], 0), r_hi = min(off[s + 1], n_rows);  // (bad offsets are flagged by enc_check_len_kernel)
+  for (int r = r_lo; r < r_hi; ++r) {
     const f32x4 y = layernorm256(*(const f32x4*)(x + (size_t)r * 256 + lane * 4), ga, gb);
     acc.x += 1.0f / (1.0f + expf(-y.x));
     acc.y += 1.0f / (1.0f + expf(-y.y));
@@ -527,8 +533,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
   const int R = n_rows;
   rp_ab_env();
   // fused QKV + attention (f16x3, every sentence <= 16 tokens): ownership windows of 65 - max_sent_len >= 49 rows
-  static const bool ab_unfused = getenv("ST_AB_ENC_UNFUSED") != nullptr;  // A/B: the two-kernel form
-  const bool fused = w->gemm_format == ST_GEMM_F16X3 && max_sent_len <= 16 && max_sent_len >= 1 && !ab_unfused;
+  const bool fused = w->gemm_format == ST_GEMM_F16X3 && max_sent_len <= 16 && max_sent_len >= 1 && !rp_enc_unfused;
   const int win = 65 - (max_sent_len < 1 ? 1 : max_sent_len), n_win = (R + win - 1) / win;
   if (fused) {
     ST_ENSURE_LDS((enc_qkv_attn16_kernel<0>), EQA_LDS);
@@ -558,14 +563,14 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       else
         ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, qsplits, st)));
       if (w->gemm_format == ST_GEMM_F16X3)
-        hipLaunchKernelGGL(enc_attn16_kernel<true>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
+        hipLaunchKernelGGL(enc_attn16_kernel<true>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, R, att);
       else
-        hipLaunchKernelGGL(enc_attn16_kernel<false>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, att);
+        hipLaunchKernelGGL(enc_attn16_kernel<false>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, R, att);
       if (max_sent_len > 16) {
         if (w->gemm_format == ST_GEMM_F16X3)
-          hipLaunchKernelGGL(enc_attn_kernel<true>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+          hipLaunchKernelGGL(enc_attn_kernel<true>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, R, att);
         else
-          hipLaunchKernelGGL(enc_attn_kernel<false>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, att);
+          hipLaunchKernelGGL(enc_attn_kernel<false>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, R, att);
       }
       ST_LAUNCH_CHECK();
     }
@@ -598,7 +603,7 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     f2.X = h; f2.n_host = R; f2.K = w->d_ff; f2.W = y.w2; f2.bias = y.b2; f2.N = 256; f2.out = x; f2.ldo = 256; f2.resid = x;
     ST_TRY(launch_rp_kchunk<EPI_RESID>(f2, R, st));
   }
-  hipLaunchKernelGGL(enc_latent_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, x, sent_off, n_sent, w->lnf_a, w->lnf_b, latent);
+  hipLaunchKernelGGL(enc_latent_kernel, dim3((n_sent + 3) / 4), dim3(256), 0, st, x, sent_off, n_sent, R, w->lnf_a, w->lnf_b, latent);
   ST_LAUNCH_CHECK();
   {  // the only synchronisation of this entry point: the flag word
     int flag[2] = {0, 0};

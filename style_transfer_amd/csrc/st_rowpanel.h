@@ -41,32 +41,46 @@
 
 #define RP_LDS ((64 * ST_LDA + 8 * 64 * 4) * 4)
 
-// Kernel-form switches (per translation unit).  tools/kbench.cpp flips them for its A/B runs; for whole-bench comparisons
-// on one box they can be set from the environment (never in production): ST_AB_TAIL32 = the round-1 32x32x16 half-layer
-// kernel, ST_AB_TAIL_ONE_PANEL = one workgroup per panel instead of the persistent loop, ST_AB_LIN32 = the 32x32x16 QKV kernel,
-// ST_AB_SCREEN32 = the 32x32x16 screening pass.
-static int rp_lin_shape16 = 1;
-static int rp_screen_shape16 = 1;
-static int rp_screen_paired = 1;
-static int rp_argmax_shape16 = 1;
-static int rp_tail_persistent = 1;
-static int rp_tail_shape16 = 1;
+// Kernel-form switches, ONE copy per library (defined in st_decode.hip; tools/kbench.cpp defines its own and flips them
+// for its A/B runs).  For same-box whole-bench comparisons (tools/ab_*.sh) they can be set from the environment, but only
+// when ST_AB_ENABLE is set as well, so that a stray ST_AB_* variable in a user's environment changes nothing; read once
+// per process (thread-safe static initialisation).  INTEGRATION.md lists them.  Never set in production.
+#ifdef ST_RP_DEFINE_SWITCHES
+#define ST_RP_SWITCH(name, value) int name = value
+#else
+#define ST_RP_SWITCH(name, value) extern int name
+#endif
+ST_RP_SWITCH(rp_lin_shape16, 1);      // ST_AB_LIN32: the 32x32x16 QKV kernel
+ST_RP_SWITCH(rp_screen_shape16, 1);   // ST_AB_SCREEN32: the 32x32x16 screening pass
+ST_RP_SWITCH(rp_screen_paired, 1);    // ST_AB_SCREEN_UNPAIRED: one key per logit in the 16x16x32 screening pass
+ST_RP_SWITCH(rp_screen_maxnorm, 0);   // ST_AB_SCREEN_MAXNORM: one bound for all columns instead of per-column norms
+ST_RP_SWITCH(rp_argmax_shape16, 1);   // ST_AB_ARGMAX32: the 32x32x16 exact argmax
+ST_RP_SWITCH(rp_tail_persistent, 1);  // ST_AB_TAIL_ONE_PANEL: one workgroup per panel instead of the persistent loop
+ST_RP_SWITCH(rp_tail_shape16, 1);     // ST_AB_TAIL32: the round-1 32x32x16 half-layer kernel
 // Below this many live rows the unfused kernels (column splits) are used instead of the half-layer kernel.  Round 3: 64 (was
 // 4096).  With a few thousand rows the unfused chain (O-projection 15 us + FFN1 38 us + FFN2 63 us per layer at 3328 rows)
 // is latency-bound on every workgroup streaming a whole weight matrix; one panel per CU through the half-layer kernel takes
-// ~45 us whatever the row count (batch-256 regime 12.9 k -> 18.3 k sentences/s, gpurun_out/small_sweep.txt).
-static int rp_tail_min_rows = 64;
+// ~45 us whatever the row count (batch-256 regime 12.9 k -> 18.3 k sentences/s, profiles/r03_small_batch.txt).
+ST_RP_SWITCH(rp_tail_min_rows, 64);   // ST_AB_TAIL_MIN_ROWS=<n>
+ST_RP_SWITCH(rp_enc_unfused, 0);      // ST_AB_ENC_UNFUSED: encoder QKV and attention as two kernels
+ST_RP_SWITCH(rp_dec_fused, 0);        // ST_AB_DEC_FUSED: decode QKV + attention in one kernel (measured negative, st_decode.hip)
+#undef ST_RP_SWITCH
 static inline void rp_ab_env() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  if (getenv("ST_AB_TAIL32")) rp_tail_shape16 = 0;
-  if (getenv("ST_AB_TAIL_ONE_PANEL")) rp_tail_persistent = 0;
-  if (getenv("ST_AB_LIN32")) rp_lin_shape16 = 0;
-  if (getenv("ST_AB_SCREEN32")) rp_screen_shape16 = 0;
-  if (getenv("ST_AB_SCREEN_UNPAIRED")) rp_screen_paired = 0;
-  if (getenv("ST_AB_ARGMAX32")) rp_argmax_shape16 = 0;
-  if (getenv("ST_AB_TAIL_MIN_ROWS")) rp_tail_min_rows = atoi(getenv("ST_AB_TAIL_MIN_ROWS"));
+  static const bool done = [] {
+    if (!getenv("ST_AB_ENABLE")) return true;
+    if (getenv("ST_AB_TAIL32")) rp_tail_shape16 = 0;
+    if (getenv("ST_AB_TAIL_ONE_PANEL")) rp_tail_persistent = 0;
+    if (getenv("ST_AB_LIN32")) rp_lin_shape16 = 0;
+    if (getenv("ST_AB_SCREEN32")) rp_screen_shape16 = 0;
+    if (getenv("ST_AB_SCREEN_UNPAIRED")) rp_screen_paired = 0;
+    if (getenv("ST_AB_SCREEN_MAXNORM")) rp_screen_maxnorm = 1;
+    if (getenv("ST_AB_ARGMAX32")) rp_argmax_shape16 = 0;
+    if (getenv("ST_AB_TAIL_MIN_ROWS")) rp_tail_min_rows = atoi(getenv("ST_AB_TAIL_MIN_ROWS"));
+    if (getenv("ST_AB_ENC_UNFUSED")) rp_enc_unfused = 1;
+    if (getenv("ST_AB_DEC_FUSED")) rp_dec_fused = 1;
+    return true;
+  }();
+  (void)done;
 }
 
 
@@ -112,9 +126,6 @@ __device__ __forceinline__ void panel_store4_nb16(float* row, int c4, f32x4 v, i
   *(h4*)(row + 128 + rp16_quad_pos(c4)) = lo;
 }
 
-// D(16 x 16) += A(16 x 32) . B(32 x 16) on f16: lane l holds A[row l & 15][k = 8 (l >> 4) .. +7], B[k = same][col l & 15];
-// D: col = l & 15, rows 4 (l >> 4) .. +3 in the four registers
-__device__ __forceinline__ f32x4 mfma16x32h(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 template <int EPI, int NW = 4, bool H = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void rp_gemm_kernel(GemmArgs a) {

@@ -123,6 +123,129 @@ struct ScorerArgs {
   float* scores_out;  // [B, n_pos + n_neg] cos / tau (optional)
 };
 
+// The optimizer update of one sentence row by one wave (lane = 4 coordinates): torch.optim.Adam's single-tensor path
+// (betas (0.9, 0.999), eps 1e-8) or one of the other rules of --victim_optimizer (flags bits 8..11).
+__device__ __forceinline__ void update_row(const ScorerArgs& a, int b, f32x4 g) {
+  const int lane = threadIdx.x & 63;
+  const int t = a.step[b] + 1;
+  const int opt = (a.flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT;
+  f32x4 m = *(const f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4);
+  f32x4 v = *(const f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4);
+  f32x4 x = *(const f32x4*)(a.latent + (size_t)b * 256 + lane * 4);
+  const float lr = a.lr[b];
+  if (opt == ST_OPT_ADAM || opt == ST_OPT_ADAMW) {
+    const double bc1 = 1.0 - pow(0.9, (double)t);
+    const double bc2 = 1.0 - pow(0.999, (double)t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2s = (float)sqrt(bc2);
+    if (opt == ST_OPT_ADAMW) x = x * (1.0f - lr * 0.01f);  // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first
+    m = m + 0.1f * (g - m);
+    v = v * 0.999f + (0.001f * g) * g;
+    f32x4 den;
+    den.x = sqrtf(v.x) / bc2s + 1e-8f;
+    den.y = sqrtf(v.y) / bc2s + 1e-8f;
+    den.z = sqrtf(v.z) / bc2s + 1e-8f;
+    den.w = sqrtf(v.w) / bc2s + 1e-8f;
+    x = x - step_size * (m / den);
+  } else if (opt == ST_OPT_SGD) {
+    x = x - lr * g;
+  } else if (opt == ST_OPT_ADAMAX) {
+    m = m + 0.1f * (g - m);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] * 0.999f, fabsf(g[q]) + 1e-8f);
+    const float clr = (float)((double)lr / (1.0 - pow(0.9, (double)t)));
+    x = x - clr * (m / v);
+  } else if (opt == ST_OPT_RMSPROP) {
+    v = v * 0.99f + (0.01f * g) * g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-8f));
+  } else {  // ST_OPT_ADAGRAD
+    v = v + g * g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-10f));
+  }
+  *(f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4) = m;
+  *(f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4) = v;
+  *(f32x4*)(a.latent + (size_t)b * 256 + lane * 4) = x;
+  if (lane == 0) a.step[b] = t;
+}
+
+// Scores, loss and d(-loss)/dp of ONE sentence row, by one wave (lane = 4 of the 256 features of p):
+// pos / neg cosine scores against the like / unlike unit vectors (siamese_contrastive.py:409-419), either objective
+// (:424-453), loss_out / scores_out.  Returns the lane's 4 components of dP.
+__device__ __forceinline__ f32x4 score_row(const ScorerArgs& a, int m0, int n, int r, int b, f32x4 p, float* cosv, float* coef,
+                                           int np, int nn, int nt, float inv_tau) {
+  const int lane = threadIdx.x & 63;
+  const float pn = fmaxf(sqrtf(wave_sum(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w)), 1e-8f);
+  for (int j = 0; j < nt; ++j) {
+    const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
+    const f32x4 zj = *(const f32x4*)(zp + lane * 4);
+    const float d = wave_sum(p.x * zj.x + p.y * zj.y + p.z * zj.z + p.w * zj.w);
+    if (lane == 0) cosv[r * 32 + j] = d / pn;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (a.scores_out && lane < nt && m0 + r < n) a.scores_out[(size_t)(m0 + r) * nt + lane] = cosv[r * 32 + lane] * inv_tau;
+  // per-lane coefficient g_j = d(-loss_ref)/d cos_j ; loss_ref = what get_contrastive_loss returns
+  float g = 0.0f, lossv = 0.0f;
+  if (a.flags & ST_F_NOT_NLL) {
+    // loss_ref = (sum neg - sum pos) / (np + nn)      (siamese_contrastive.py:424-436)
+    const float c = inv_tau / (float)nt;
+    if (lane < nt) g = lane < np ? c : -c;
+    float sacc = 0.0f;
+    for (int j = 0; j < nt; ++j) sacc += (j < np ? -1.0f : 1.0f) * cosv[r * 32 + j] * inv_tau;
+    lossv = sacc / (float)nt;
+  } else {
+    // loss_i = -log_softmax([pos_i, neg_0..])[0]; loss_ref = mean_i (or min_i with --just_use_one)  (:438-453)
+    float negmax = -INFINITY;
+    for (int k = 0; k < nn; ++k) negmax = fmaxf(negmax, cosv[r * 32 + np + k] * inv_tau);
+    int best_i = 0;
+    float best_l = INFINITY, mean_l = 0.0f;
+    for (int i = 0; i < np; ++i) {
+      const float si = cosv[r * 32 + i] * inv_tau;
+      const float M = fmaxf(si, negmax);
+      float den = expf(si - M);
+      for (int k = 0; k < nn; ++k) den += expf(cosv[r * 32 + np + k] * inv_tau - M);
+      const float li = M + logf(den) - si;
+      mean_l += li;
+      if (li < best_l) { best_l = li; best_i = i; }
+    }
+    const bool one = a.flags & ST_F_JUST_USE_ONE;
+    lossv = one ? best_l : mean_l / (float)np;
+    if (lane < nt) {
+      float cj = 0.0f;  // d loss_ref / d s_lane
+      const float sl = cosv[r * 32 + lane] * inv_tau;
+      for (int i = 0; i < np; ++i) {
+        const float wi = one ? (i == best_i ? 1.0f : 0.0f) : 1.0f / (float)np;
+        if (wi == 0.0f) continue;
+        const float si = cosv[r * 32 + i] * inv_tau;
+        const float M = fmaxf(si, negmax);
+        float den = expf(si - M);
+        for (int k = 0; k < nn; ++k) den += expf(cosv[r * 32 + np + k] * inv_tau - M);
+        if (lane < np) {
+          if (i == lane) cj += wi * (expf(si - M) / den - 1.0f);
+        } else {
+          cj += wi * expf(sl - M) / den;
+        }
+      }
+      g = -cj * inv_tau;
+    }
+  }
+  if (lane < 32) coef[r * 32 + lane] = lane < nt ? g : 0.0f;
+  __builtin_amdgcn_wave_barrier();
+  f32x4 gs = {0, 0, 0, 0};
+  float gc = 0.0f;
+  for (int j = 0; j < nt; ++j) {
+    const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
+    const f32x4 zj = *(const f32x4*)(zp + lane * 4);
+    const float gj = coef[r * 32 + j];
+    gs += gj * zj;
+    gc += gj * cosv[r * 32 + j];
+  }
+  const f32x4 dp = gs / pn - (gc / (pn * pn)) * p;
+  if (lane == 0 && a.loss_out && m0 + r < n) a.loss_out[m0 + r] = lossv;
+  return dp;
+}
+
 template <bool EDIT>
 __global__ __launch_bounds__(64 * SC_NW, 4) void scorer_kernel(ScorerArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -183,74 +306,8 @@ __global__ __launch_bounds__(64 * SC_NW, 4) void scorer_kernel(ScorerArgs a) {
       const int r = wave * SC_RPW + rr;
       const int b = min(m0 + r, n - 1);
       const f32x4 p = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
-      const float pn = fmaxf(sqrtf(wave_sum(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w)), 1e-8f);
-      for (int j = 0; j < nt; ++j) {
-        const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
-        const f32x4 zj = *(const f32x4*)(zp + lane * 4);
-        const float d = wave_sum(p.x * zj.x + p.y * zj.y + p.z * zj.z + p.w * zj.w);
-        if (lane == 0) cosv[r * 32 + j] = d / pn;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (a.scores_out && lane < nt && m0 + r < n) a.scores_out[(size_t)(m0 + r) * nt + lane] = cosv[r * 32 + lane] * inv_tau;
-      // per-lane coefficient g_j = d(-loss_ref)/d cos_j ; loss_ref = what get_contrastive_loss returns
-      float g = 0.0f, lossv = 0.0f;
-      if (a.flags & ST_F_NOT_NLL) {
-        // loss_ref = (sum neg - sum pos) / (np + nn)      (siamese_contrastive.py:424-436)
-        const float c = inv_tau / (float)nt;
-        if (lane < nt) g = lane < np ? c : -c;
-        float sacc = 0.0f;
-        for (int j = 0; j < nt; ++j) sacc += (j < np ? -1.0f : 1.0f) * cosv[r * 32 + j] * inv_tau;
-        lossv = sacc / (float)nt;
-      } else {
-        // loss_i = -log_softmax([pos_i, neg_0..])[0]; loss_ref = mean_i (or min_i with --just_use_one)  (:438-453)
-        float negmax = -INFINITY;
-        for (int k = 0; k < nn; ++k) negmax = fmaxf(negmax, cosv[r * 32 + np + k] * inv_tau);
-        int best_i = 0;
-        float best_l = INFINITY, mean_l = 0.0f;
-        for (int i = 0; i < np; ++i) {
-          const float si = cosv[r * 32 + i] * inv_tau;
-          const float M = fmaxf(si, negmax);
-          float den = expf(si - M);
-          for (int k = 0; k < nn; ++k) den += expf(cosv[r * 32 + np + k] * inv_tau - M);
-          const float li = M + logf(den) - si;
-          mean_l += li;
-          if (li < best_l) { best_l = li; best_i = i; }
-        }
-        const bool one = a.flags & ST_F_JUST_USE_ONE;
-        lossv = one ? best_l : mean_l / (float)np;
-        if (lane < nt) {
-          float cj = 0.0f;  // d loss_ref / d s_lane
-          const float sl = cosv[r * 32 + lane] * inv_tau;
-          for (int i = 0; i < np; ++i) {
-            const float wi = one ? (i == best_i ? 1.0f : 0.0f) : 1.0f / (float)np;
-            if (wi == 0.0f) continue;
-            const float si = cosv[r * 32 + i] * inv_tau;
-            const float M = fmaxf(si, negmax);
-            float den = expf(si - M);
-            for (int k = 0; k < nn; ++k) den += expf(cosv[r * 32 + np + k] * inv_tau - M);
-            if (lane < np) {
-              if (i == lane) cj += wi * (expf(si - M) / den - 1.0f);
-            } else {
-              cj += wi * expf(sl - M) / den;
-            }
-          }
-          g = -cj * inv_tau;
-        }
-      }
-      if (lane < 32) coef[r * 32 + lane] = lane < nt ? g : 0.0f;
-      __builtin_amdgcn_wave_barrier();
-      f32x4 gs = {0, 0, 0, 0};
-      float gc = 0.0f;
-      for (int j = 0; j < nt; ++j) {
-        const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
-        const f32x4 zj = *(const f32x4*)(zp + lane * 4);
-        const float gj = coef[r * 32 + j];
-        gs += gj * zj;
-        gc += gj * cosv[r * 32 + j];
-      }
-      const f32x4 dp = gs / pn - (gc / (pn * pn)) * p;
+      const f32x4 dp = score_row(a, m0, n, r, b, p, cosv, coef, np, nn, nt, inv_tau);
       *(f32x4*)(bufA + r * SC_LD + lane * 4) = dp;
-      if (lane == 0 && a.loss_out && m0 + r < n) a.loss_out[m0 + r] = lossv;
     }
     __syncthreads();
     // ---- backward to the latent ----
@@ -266,7 +323,7 @@ __global__ __launch_bounds__(64 * SC_NW, 4) void scorer_kernel(ScorerArgs a) {
     __syncthreads();
     tile_linear<512, 256, false, BWD_NONE>(bufA, bufB, a.w.s1_wt, nullptr, nullptr, 0);
     __syncthreads();
-    // ---- Adam (torch.optim.Adam single-tensor path, betas (0.9, 0.999), eps 1e-8) ----
+    // ---- optimizer step on the latent ----
     for (int rr = 0; rr < SC_RPW; ++rr) {
       const int r = wave * SC_RPW + rr;
       const int b = m0 + r;
@@ -274,48 +331,240 @@ __global__ __launch_bounds__(64 * SC_NW, 4) void scorer_kernel(ScorerArgs a) {
       const f32x4 g = *(const f32x4*)(bufB + r * SC_LD + lane * 4);
       if (a.grad_out) *(f32x4*)(a.grad_out + (size_t)b * 256 + lane * 4) = g;
       if (a.active && !a.active[b]) continue;
-      const int t = a.step[b] + 1;
-      const int opt = (a.flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT;
-      f32x4 m = *(const f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4);
-      f32x4 v = *(const f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4);
-      f32x4 x = *(const f32x4*)(a.latent + (size_t)b * 256 + lane * 4);
-      const float lr = a.lr[b];
-      if (opt == ST_OPT_ADAM || opt == ST_OPT_ADAMW) {
-        const double bc1 = 1.0 - pow(0.9, (double)t);
-        const double bc2 = 1.0 - pow(0.999, (double)t);
-        const float step_size = (float)((double)lr / bc1);
-        const float bc2s = (float)sqrt(bc2);
-        if (opt == ST_OPT_ADAMW) x = x * (1.0f - lr * 0.01f);  // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first
-        m = m + 0.1f * (g - m);
-        v = v * 0.999f + (0.001f * g) * g;
-        f32x4 den;
-        den.x = sqrtf(v.x) / bc2s + 1e-8f;
-        den.y = sqrtf(v.y) / bc2s + 1e-8f;
-        den.z = sqrtf(v.z) / bc2s + 1e-8f;
-        den.w = sqrtf(v.w) / bc2s + 1e-8f;
-        x = x - step_size * (m / den);
-      } else if (opt == ST_OPT_SGD) {
-        x = x - lr * g;
-      } else if (opt == ST_OPT_ADAMAX) {
-        m = m + 0.1f * (g - m);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] * 0.999f, fabsf(g[q]) + 1e-8f);
-        const float clr = (float)((double)lr / (1.0 - pow(0.9, (double)t)));
-        x = x - clr * (m / v);
-      } else if (opt == ST_OPT_RMSPROP) {
-        v = v * 0.99f + (0.01f * g) * g;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-8f));
-      } else {  // ST_OPT_ADAGRAD
-        v = v + g * g;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-10f));
-      }
-      *(f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4) = m;
-      *(f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4) = v;
-      *(f32x4*)(a.latent + (size_t)b * 256 + lane * 4) = x;
-      if (lane == 0) a.step[b] = t;
+      update_row(a, b, g);
     }
+  }
+}
+
+// ================================================================================================
+// f16x3 form (StScorerWeights.gemm_format == ST_GEMM_F16X3): the same step on v_mfma_f32_16x16x32_f16 with split
+// operands x = hi + lo, three products per term (hi.hi + lo.hi + hi.lo, f32 accumulate), i.e. 16/3 of the exact-f32
+// MFMA rate: the f32 kernel above is MFMA-bound (75 MFLOP per 32-sentence tile = 123 us of one CU's f32 matrix pipe).
+//  * Weights: the packed f16x3 image of st_pack_weight (the 32x32x16 layout read through the 16x16x32 lane addresses,
+//    as in st_rowpanel.h), of W PRE-SCALED by a power of two so that max |W| lies in [2^13, 2^14): BatchNorm-folded
+//    weights are small (Predictor fc1: rms 0.003) and an unscaled lo part would be an f16 subnormal with a handful of
+//    bits.  The result is multiplied by unscale = 1 / scale (exact).  W is the A operand: a lane ends up with 4
+//    consecutive output features of ONE sentence, stored to LDS as packed halves (two 8-byte stores).
+//  * Activations: [32 rows][SC_LD dwords], hi halves of feature k at dwords [0, K/2), lo halves at [256, 256 + K/2).
+//    Forward activations are O(1) and go in unscaled; the backward pass starts from dP, which is 1e-5 .. 1e-2: every
+//    row of dP is scaled by a power of two that brings its largest element to [512, 1024) and the final gradient row
+//    is multiplied by the inverse (rowinv), so small gradients keep f32-grade relative precision.
+//  * ReLU / LeakyReLU masks: the lane that computes (sentence, feature) in the forward layer is the lane that needs
+//    that mask bit in the backward layer of the same width, so the masks live in three registers per lane, not in LDS.
+//  * A value beyond the f16 range (it would turn into inf - inf inside the products) raises a sticky device flag that
+//    st_scorer_status reports.
+// ================================================================================================
+#define SH_LO 256
+static __device__ int g_scorer_range_flag;
+
+template <int K, int N, bool FWD, int ACT, bool OUT_F32>
+__device__ __forceinline__ void tile_linear16(float* Xs, const float* __restrict__ W, const float* __restrict__ bias,
+                                              float unscale, uint32_t& mask, const float* rowinv, int& bad) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  constexpr int DS = K / 32;            // double k-steps
+  constexpr int NFT = N / 16 / SC_NW;   // 16-feature tiles per wave: tile t = wave + 8 i
+  static_assert(NFT >= 1 && N % (16 * SC_NW) == 0 && K % 32 == 0, "layer shape");
+  constexpr int R = 2;                  // W ring depth in double steps
+  static_assert(DS % R == 0, "ring");
+  const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, N * K * 4, 0x00020000);
+  auto wfetch = [&](int d, f32x4 (&dst)[NFT][2]) {
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+      const int t = wave + SC_NW * i;
+      const int off = (t >> 1) * (K / 16) * 2048 + d * 4096 + (t & 1) * 256;  // wave-uniform
+      dst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl, off, 0));
+      dst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1024, off, 0));
+    }
+  };
+  f32x4 ring[R][NFT][2];
+#pragma unroll
+  for (int j = 0; j < R; ++j) wfetch(j, ring[j]);
+  f32x4 acc[NFT][2];
+#pragma unroll
+  for (int i = 0; i < NFT; ++i) {
+    acc[i][0] = (f32x4){0, 0, 0, 0};
+    acc[i][1] = (f32x4){0, 0, 0, 0};
+  }
+  const float* xb = Xs + r16 * SC_LD + 4 * g;
+#pragma unroll
+  for (int d = 0; d < DS; ++d) {
+    f32x4 wf[NFT][2];
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+      wf[i][0] = ring[d % R][i][0];
+      wf[i][1] = ring[d % R][i][1];
+    }
+    if (d + R < DS) wfetch(d + R, ring[d % R]);
+    const h8 x0h = as_h8(*(const f32x4*)(xb + 16 * d)), x0l = as_h8(*(const f32x4*)(xb + SH_LO + 16 * d));
+    const h8 x1h = as_h8(*(const f32x4*)(xb + 16 * SC_LD + 16 * d)), x1l = as_h8(*(const f32x4*)(xb + 16 * SC_LD + SH_LO + 16 * d));
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+      acc[i][0] = mfma16x32h(as_h8(wf[i][0]), x0h, acc[i][0]);
+      acc[i][1] = mfma16x32h(as_h8(wf[i][0]), x1h, acc[i][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+      acc[i][0] = mfma16x32h(as_h8(wf[i][1]), x0h, acc[i][0]);
+      acc[i][1] = mfma16x32h(as_h8(wf[i][1]), x1h, acc[i][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+      acc[i][0] = mfma16x32h(as_h8(wf[i][0]), x0l, acc[i][0]);
+      acc[i][1] = mfma16x32h(as_h8(wf[i][0]), x1l, acc[i][1]);
+    }
+  }
+  __syncthreads();  // every wave has read its last input fragment: the layer is written IN PLACE
+#pragma unroll
+  for (int i = 0; i < NFT; ++i)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int f0 = 16 * (wave + SC_NW * i) + 4 * g;
+      const int row = 16 * rt + r16;
+      f32x4 v = acc[i][rt] * unscale;
+      if (FWD) v += *(const f32x4*)(bias + f0);
+      if (ACT != ACT_NONE) {
+        const int sh = (2 * i + rt) * 4;
+        if (FWD) {
+          uint32_t nib = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool on = v[j] > 0.0f;
+            nib |= (on ? 1u : 0u) << j;
+            v[j] = on ? v[j] : (ACT == ACT_RELU ? 0.0f : 0.2f * v[j]);
+          }
+          mask |= nib << sh;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool on = (mask >> (sh + j)) & 1u;
+            v[j] = on ? v[j] : (ACT == ACT_RELU ? 0.0f : 0.2f * v[j]);
+          }
+        }
+      }
+      if (OUT_F32) {
+        if (!FWD) v = v * rowinv[row];
+        *(f32x4*)(Xs + row * SC_LD + f0) = v;
+      } else {
+        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        bad |= !(m <= 65504.0f);
+        h4 hi, lo;
+        split_f16(v, hi, lo);
+        *(h4*)(Xs + row * SC_LD + (f0 >> 1)) = hi;
+        *(h4*)(Xs + row * SC_LD + SH_LO + (f0 >> 1)) = lo;
+      }
+    }
+}
+
+#define SC16_LDS_BYTES ((SC_BUF + 32 * 32 * 2 + 32) * 4)
+
+template <bool EDIT>
+__global__ __launch_bounds__(64 * SC_NW, 4) void scorer16_kernel(ScorerArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* buf = smem;                 // [32][SC_LD]: the one activation buffer
+  float* cosv = smem + SC_BUF;       // [32][32]
+  float* coef = cosv + 32 * 32;      // [32][32]
+  float* rowinv = coef + 32 * 32;    // [32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = a.n;
+  const int m0 = blockIdx.x * SC_ROWS;
+  if (m0 >= n) return;
+  const float* xin = EDIT ? a.latent : a.x;
+  int bad = 0;
+  // latent tile -> split halves (32 rows x 64 float4 = 2048)
+#pragma unroll
+  for (int i = 0; i < 2048 / (64 * SC_NW); ++i) {
+    const int f = tid + i * 64 * SC_NW;
+    const int r = f >> 6, c4 = f & 63;
+    const f32x4 v = *(const f32x4*)(xin + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    bad |= !(m <= 65504.0f);
+    h4 hi, lo;
+    split_f16(v, hi, lo);
+    *(h4*)(buf + r * SC_LD + c4 * 2) = hi;
+    *(h4*)(buf + r * SC_LD + SH_LO + c4 * 2) = lo;
+  }
+  __syncthreads();
+  const float* us = a.w.unscale;
+  uint32_t m1 = 0, m2 = 0, mq = 0, none = 0;
+  const bool simplest = EDIT && (a.flags & ST_F_SIMPLEST);
+  tile_linear16<256, 512, true, ACT_RELU, false>(buf, a.w.s1_w, a.w.s1_b, us[0], m1, nullptr, bad);
+  __syncthreads();
+  tile_linear16<512, 512, true, ACT_RELU, false>(buf, a.w.s2_w, a.w.s2_b, us[1], m2, nullptr, bad);
+  __syncthreads();
+  if (!EDIT || simplest)
+    tile_linear16<512, 256, true, ACT_NONE, true>(buf, a.w.s3_w, a.w.s3_b, us[2], none, nullptr, bad);
+  else
+    tile_linear16<512, 256, true, ACT_NONE, false>(buf, a.w.s3_w, a.w.s3_b, us[2], none, nullptr, bad);
+  __syncthreads();
+
+  if (!EDIT) {
+    for (int rr = 0; rr < SC_RPW; ++rr) {
+      const int r = wave * SC_RPW + rr;
+      if (m0 + r >= n) continue;
+      f32x4 v = *(const f32x4*)(buf + r * SC_LD + lane * 4);
+      if (a.unit) {
+        const float nn = sqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
+        v = v / fmaxf(nn, 1e-8f);
+      }
+      *(f32x4*)(a.z + (size_t)(m0 + r) * 256 + lane * 4) = v;
+    }
+    if (bad) g_scorer_range_flag = 1;
+    return;
+  } else {
+    if (!simplest) {
+      tile_linear16<256, 128, true, ACT_LRELU, false>(buf, a.w.p1_w, a.w.p1_b, us[3], mq, nullptr, bad);
+      __syncthreads();
+      tile_linear16<128, 256, true, ACT_NONE, true>(buf, a.w.p2_w, a.w.p2_b, us[4], none, nullptr, bad);
+      __syncthreads();
+    }
+    // ---- scores, loss, dL/dp: p as f32 in buf[., 0:256]; dP goes back as scaled split halves ----
+    const int np = a.n_pos, nn = a.n_neg, nt = np + nn;
+    const float inv_tau = 1.0f / a.tau;
+    for (int rr = 0; rr < SC_RPW; ++rr) {
+      const int r = wave * SC_RPW + rr;
+      const int b = min(m0 + r, n - 1);
+      const f32x4 p = *(const f32x4*)(buf + r * SC_LD + lane * 4);
+      const f32x4 dp = score_row(a, m0, n, r, b, p, cosv, coef, np, nn, nt, inv_tau);
+      const float mx = wave_max(fmaxf(fmaxf(fabsf(dp.x), fabsf(dp.y)), fmaxf(fabsf(dp.z), fabsf(dp.w))));
+      // power of two that brings the row's largest |dP| into [512, 1024); 1 for a zero / non-finite row
+      const int ex = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
+      const bool ok = mx > 0.0f && ex > -100 && ex < 100;
+      const float sc = ok ? __uint_as_float((uint32_t)(127 + 9 - ex) << 23) : 1.0f;
+      if (lane == 0) rowinv[r] = ok ? __uint_as_float((uint32_t)(127 - 9 + ex) << 23) : 1.0f;
+      const f32x4 v = dp * sc;
+      const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+      bad |= !(m <= 65504.0f);
+      h4 hi, lo;
+      split_f16(v, hi, lo);
+      *(h4*)(buf + r * SC_LD + lane * 2) = hi;
+      *(h4*)(buf + r * SC_LD + SH_LO + lane * 2) = lo;
+    }
+    __syncthreads();
+    // ---- backward to the latent ----
+    if (!simplest) {
+      tile_linear16<256, 128, false, BWD_LRELU, false>(buf, a.w.p2_wt, nullptr, us[4], mq, nullptr, bad);
+      __syncthreads();
+      tile_linear16<128, 256, false, BWD_NONE, false>(buf, a.w.p1_wt, nullptr, us[3], none, nullptr, bad);
+      __syncthreads();
+    }
+    tile_linear16<256, 512, false, BWD_RELU, false>(buf, a.w.s3_wt, nullptr, us[2], m2, nullptr, bad);
+    __syncthreads();
+    tile_linear16<512, 512, false, BWD_RELU, false>(buf, a.w.s2_wt, nullptr, us[1], m1, nullptr, bad);
+    __syncthreads();
+    tile_linear16<512, 256, false, BWD_NONE, true>(buf, a.w.s1_wt, nullptr, us[0], none, rowinv, bad);
+    __syncthreads();
+    for (int rr = 0; rr < SC_RPW; ++rr) {
+      const int r = wave * SC_RPW + rr;
+      const int b = m0 + r;
+      if (b >= n) continue;
+      const f32x4 g = *(const f32x4*)(buf + r * SC_LD + lane * 4);
+      if (a.grad_out) *(f32x4*)(a.grad_out + (size_t)b * 256 + lane * 4) = g;
+      if (a.active && !a.active[b]) continue;
+      update_row(a, b, g);
+    }
+    if (bad) g_scorer_range_flag = 1;
   }
 }
 
@@ -325,11 +574,20 @@ static int check_scorer(const StScorerWeights* w) {
   ST_CHECK_ARG(w != nullptr, "scorer weights struct is NULL");
   ST_CHECK_ARG(w->s1_w && w->s1_wt && w->s1_b && w->s2_w && w->s2_wt && w->s2_b && w->s3_w && w->s3_wt && w->s3_b,
                "NULL SiameseNet weight pointer");
+  ST_CHECK_ARG(w->gemm_format == ST_GEMM_F32 || w->gemm_format == ST_GEMM_F16X3, "scorer gemm_format=%d unknown", w->gemm_format);
+  if (w->gemm_format == ST_GEMM_F16X3)
+    for (int i = 0; i < 5; ++i) ST_CHECK_ARG(w->unscale[i] > 0.0f, "scorer unscale[%d]=%g must be > 0 in the f16x3 format", i, (double)w->unscale[i]);
   return ST_OK;
 }
 
 template <bool EDIT>
 static int launch_scorer(const ScorerArgs& a, hipStream_t st) {
+  if (a.w.gemm_format == ST_GEMM_F16X3) {
+    ST_ENSURE_LDS((scorer16_kernel<EDIT>), SC16_LDS_BYTES);
+    hipLaunchKernelGGL(scorer16_kernel<EDIT>, dim3((a.n + SC_ROWS - 1) / SC_ROWS), dim3(64 * SC_NW), SC16_LDS_BYTES, st, a);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
   ST_ENSURE_LDS((scorer_kernel<EDIT>), SC_LDS_BYTES);
   hipLaunchKernelGGL(scorer_kernel<EDIT>, dim3((a.n + SC_ROWS - 1) / SC_ROWS), dim3(64 * SC_NW), SC_LDS_BYTES, st, a);
   ST_LAUNCH_CHECK();
@@ -371,4 +629,15 @@ extern "C" int st_scorer_edit_step(const StScorerWeights* w, float* latent, floa
   a.n_pos = n_pos; a.n_neg = n_neg; a.lr = lr; a.step = step; a.active = active; a.tau = tau; a.flags = flags;
   a.loss_out = loss_out; a.grad_out = grad_out; a.scores_out = scores_out;
   return launch_scorer<true>(a, (hipStream_t)stream);
+}
+
+/* sticky f16-range flag of the f16x3 scorer kernels (see st_kernels.h) */
+extern "C" int st_scorer_status(int* out_of_range, int reset) {
+  ST_CHECK_ARG(out_of_range != nullptr, "st_scorer_status: NULL output");
+  ST_HIP(hipMemcpyFromSymbol(out_of_range, HIP_SYMBOL(g_scorer_range_flag), sizeof(int)));
+  if (reset && *out_of_range) {
+    const int zero = 0;
+    ST_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scorer_range_flag), &zero, sizeof(int)));
+  }
+  return ST_OK;
 }

@@ -217,7 +217,11 @@ def train_ae_main(args, vocab_size, data_path, save_path, device, rank, world, l
     log('Loading Dataset, Shuffle=True')
     log('ori_file_list = {}'.format(files))
     print('Random Seed is set to 234')
-    data = AttackSet.from_json(files, vocab_size, args.id_unk, args.max_sequence_length, args.pos_num, 0)
+    if args.batch_size % 32 != 0 or args.batch_size <= 0:
+        raise SystemExit("--train_ae needs --batch_size to be a positive multiple of 32 (the in-batch constraint kernel); got %d" % args.batch_size)
+    # create_ae_data_loader calls create_batches with pos_num=None / neg_num=None (siamese_contrastive.py:950-995): the number
+    # of like views always comes from the file's sim_num, whatever --pos_num says
+    data = AttackSet.from_json(files, vocab_size, args.id_unk, args.max_sequence_length, None, 0)
     trainer = AETrainer(sd, AETrainConfig(bata=args.bata, tau=args.tau), device)
     os.makedirs(save_path, exist_ok=True)
     train_ae_model_constraint(trainer, data, args.batch_size, args.ae_epochs, log, save_path)
@@ -310,7 +314,7 @@ def main(argv=None):
     if not os.path.exists(pp):
         print('Predictor Net Path Not Exist')
         sys.exit(0)
-    scorer = W.ScorerWeights(W.load_state_dict_file(sp), W.load_state_dict_file(pp), device)
+    scorer = W.ScorerWeights(W.load_state_dict_file(sp), W.load_state_dict_file(pp), device, gemm_format=args.gemm_format)
 
     files = [os.path.join(data_path, 'neg10_pos10_test0.json'), os.path.join(data_path, 'neg10_pos10_test1.json')]
     if args.reverse_order:

@@ -136,22 +136,42 @@ def fold_bn(w, b, bn_w, bn_b, mean, var, eps=1e-5):
 
 
 class ScorerWeights(_Packed):
-    """SiameseNet + Predictor (siamese_contrastive.py:29-86) from their two state-dicts."""
+    """SiameseNet + Predictor (siamese_contrastive.py:29-86) from their two state-dicts.
+    gemm_format "f16x3" (default): split-f16 operands on the f16 matrix cores, three products per term; every matrix is
+    pre-scaled by a power of two (exact) so that its largest element lies in [2^13, 2^14) and the kernel undoes the scale
+    (StScorerWeights.unscale).  "f32": exact f32 MFMA."""
 
-    def __init__(self, siamese_sd: dict, predictor_sd, device):
-        super().__init__(device)
+    def __init__(self, siamese_sd: dict, predictor_sd, device, gemm_format: str = "f16x3"):
+        super().__init__(device, gemm_format)
+        if gemm_format not in _lib.GEMM_FORMATS:
+            raise ValueError("gemm_format %r: expected one of %s" % (gemm_format, sorted(_lib.GEMM_FORMATS)))
         if siamese_sd["fc1.weight"].shape != (512, 256):
             raise _lib.StError("latent_size %d unsupported: kernels are specialised for 256" % siamese_sd["fc1.weight"].shape[1])
         self.c = _lib.StScorerWeights()
         c = self.c
+        c.gemm_format = _lib.GEMM_FORMATS[gemm_format]
         w1, b1 = fold_bn(siamese_sd["fc1.weight"], siamese_sd["fc1.bias"], siamese_sd["norm1.weight"],
                          siamese_sd["norm1.bias"], siamese_sd["norm1.running_mean"], siamese_sd["norm1.running_var"])
         w2, b2 = fold_bn(siamese_sd["fc2.weight"], siamese_sd["fc2.bias"], siamese_sd["norm2.weight"],
                          siamese_sd["norm2.bias"], siamese_sd["norm2.running_mean"], siamese_sd["norm2.running_var"])
         w3, b3 = siamese_sd["fc3.weight"], siamese_sd["fc3.bias"]
-        c.s1_w, c.s1_wt, c.s1_b = self.packed(w1), self.packed(w1.t()), self.dev(b1)
-        c.s2_w, c.s2_wt, c.s2_b = self.packed(w2), self.packed(w2.t()), self.dev(b2)
-        c.s3_w, c.s3_wt, c.s3_b = self.packed(w3), self.packed(w3.t()), self.dev(b3)
+
+        def pair(i, w):
+            """-> (packed W, packed W^T); in the f16x3 format of W * 2^e with max |W| 2^e in [2^13, 2^14)"""
+            w = w.float()
+            if gemm_format == "f16x3":
+                big = float(w.abs().max())
+                if not (0.0 < big < float("inf")):
+                    raise _lib.StError("scorer layer %d has no finite non-zero weight" % i)
+                e = 13 - math.floor(math.log2(big))
+                w = w * (2.0 ** e)
+                c.unscale[i] = 2.0 ** -e
+            else:
+                c.unscale[i] = 1.0
+            return self.packed(w), self.packed(w.t())
+        (c.s1_w, c.s1_wt), c.s1_b = pair(0, w1), self.dev(b1)
+        (c.s2_w, c.s2_wt), c.s2_b = pair(1, w2), self.dev(b2)
+        (c.s3_w, c.s3_wt), c.s3_b = pair(2, w3), self.dev(b3)
         if predictor_sd is not None:
             u1, c1 = fold_bn(predictor_sd["fc1.weight"], predictor_sd["fc1.bias"], predictor_sd["norm1.weight"],
                              predictor_sd["norm1.bias"], predictor_sd["norm1.running_mean"], predictor_sd["norm1.running_var"])
@@ -161,8 +181,17 @@ class ScorerWeights(_Packed):
             u1p = torch.zeros(128, 256); u1p[:hid] = u1
             c1p = torch.zeros(128); c1p[:hid] = c1
             u2p = torch.zeros(256, 128); u2p[:, :hid] = predictor_sd["fc2.weight"]
-            c.p1_w, c.p1_wt, c.p1_b = self.packed(u1p), self.packed(u1p.t()), self.dev(c1p)
-            c.p2_w, c.p2_wt, c.p2_b = self.packed(u2p), self.packed(u2p.t()), self.dev(predictor_sd["fc2.bias"])
+            (c.p1_w, c.p1_wt), c.p1_b = pair(3, u1p), self.dev(c1p)
+            (c.p2_w, c.p2_wt), c.p2_b = pair(4, u2p), self.dev(predictor_sd["fc2.bias"])
+
+    def check_range(self):
+        """raises when an f16x3 scorer kernel saw a value outside the f16 range since the last check (synchronises)"""
+        import ctypes as C
+        flag = C.c_int(0)
+        _lib.check(_lib.lib().st_scorer_status(C.byref(flag), 1), "st_scorer_status")
+        if flag.value:
+            raise _lib.StError("scorer (f16x3 format): an activation or gradient left the f16 range; the edited latents are "
+                               "invalid - build ScorerWeights with gemm_format='f32'")
 
 
 class ClassifierWeights(_Packed):

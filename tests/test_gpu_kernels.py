@@ -34,10 +34,10 @@ def ae(request, ae_sd_torch, dev):
     return AEWeights(ae_sd_torch, dev, gemm_format=request.param)
 
 
-@pytest.fixture(scope="module")
-def scorer(scorer_sd_torch, dev):
+@pytest.fixture(scope="module", params=FORMATS)
+def scorer(request, scorer_sd_torch, dev):
     from style_transfer_amd.weights import ScorerWeights
-    return ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev)
+    return ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev, gemm_format=request.param)
 
 
 def some_sentences(n, seed=0):
@@ -514,3 +514,94 @@ def test_fgim_matches_reference_and_oracle(dev, ae, ae_sd, id_to_word):
             first = int(np.nonzero(ids[r] != ref_ids[r])[0][0])
             assert ref_gap[r, first] < 1e-3, (r, first, float(ref_gap[r, first]))
     assert (ids.reshape(len(big), -1, 59)[-1] != ids.reshape(len(big), -1, 59)[0]).any()   # the texts do change
+
+
+@pytest.mark.parametrize("kind", ["negative", "non_monotonic", "beyond_rows"])
+def test_encoder_rejects_bad_sentence_offsets_without_a_fault(dev, ae, kind):
+    """Offsets come from the caller.  The kernels run before the host reads the verdict of the offset check, so every one
+    of them must stay inside its buffers on offsets that are negative, go backwards or point past the rows; the call then
+    returns ST_EINVAL.  A good call afterwards still gives the right latents (nothing was clobbered)."""
+    from style_transfer_amd import ops, _lib
+    from style_transfer_amd.data import pack_sentences
+    sents = some_sentences(300, seed=21)
+    tok, pos, off, mx = pack_sentences(sents)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    good = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx)
+    bad = off.copy()
+    if kind == "negative":
+        bad[5] = -7000
+    elif kind == "non_monotonic":
+        bad[100], bad[101] = bad[101] + 3, bad[100]
+    else:
+        bad[200:] += 50000
+    with pytest.raises(_lib.StError):
+        ops.encode_latent(ae, t(tok), t(pos), t(bad), len(sents), mx)
+    torch.cuda.synchronize()
+    again = ops.encode_latent(ae, t(tok), t(pos), t(off), len(sents), mx)
+    assert torch.equal(good, again)
+
+
+def test_scorer_gradient_accuracy_against_float64(dev, scorer_sd_torch, scorer, ae_sd_torch):
+    """Both scorer formats are f32-grade: d(-loss)/d(latent) of the --not_nll objective against a float64 torch evaluation
+    (eval-mode BatchNorm, siamese_contrastive.py:367-436) on the encoder latents of 256 real test sentences.  The error is
+    measured against the row's largest gradient component; its median must be below 5e-7 and its 99th percentile below
+    2e-5 (observed: 1e-7 / 2.5e-6 in both formats; the tail are coordinates next to a ReLU kink)."""
+    from style_transfer_amd import ops
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet
+    from style_transfer_amd.weights import AEWeights
+    s, p = scorer_sd_torch
+    ae = AEWeights(ae_sd_torch, dev)
+    data = AttackSet.from_json([os.path.join(GOLD, "yelp", "neg10_pos10_test%d.json" % i) for i in (0, 1)], ae.vocab).span(0, 256)
+    B = len(data)
+    r = AttackRunner(ae, None, AttackConfig(), dev)
+    lat = r.encode_prepared(r.prepare(data))
+    x, like, unlike = lat[:B].clone(), lat[B:B + 10 * B], lat[B + 10 * B:]
+    d = lambda t: t.double()
+    bn = lambda h, sd, k: (h - d(sd[k + ".running_mean"])) / torch.sqrt(d(sd[k + ".running_var"]) + 1e-5) * d(sd[k + ".weight"]) + d(sd[k + ".bias"])
+
+    def siamese64(xx):
+        h = torch.relu(bn(xx @ d(s["fc1.weight"]).t() + d(s["fc1.bias"]), s, "norm1"))
+        h = torch.relu(bn(h @ d(s["fc2.weight"]).t() + d(s["fc2.bias"]), s, "norm2"))
+        return h @ d(s["fc3.weight"]).t() + d(s["fc3.bias"])
+    unit = lambda z: z / z.norm(dim=1, keepdim=True)
+    lz64, uz64 = unit(siamese64(d(like.cpu()))).view(B, 10, 256), unit(siamese64(d(unlike.cpu()))).view(B, 10, 256)
+    x64 = d(x.cpu()).requires_grad_(True)
+    z = siamese64(x64)
+    q = torch.nn.functional.leaky_relu(bn(z @ d(p["fc1.weight"]).t() + d(p["fc1.bias"]), p, "norm1"), 0.2)
+    pp = unit(q @ d(p["fc2.weight"]).t() + d(p["fc2.bias"]))
+    loss = ((((pp[:, None, :] * uz64).sum(-1) - (pp[:, None, :] * lz64).sum(-1)) / 0.1).sum(1) / 20).sum()
+    (-loss).backward()
+    g64 = x64.grad
+    lz = ops.scorer_embed(scorer, like).view(B, 10, 256)
+    uz = ops.scorer_embed(scorer, unlike).view(B, 10, 256)
+    assert (lz.cpu().double() - lz64).abs().max() < 2e-6
+    xx = x.clone()
+    m, v = torch.zeros_like(xx), torch.zeros_like(xx)
+    step = torch.zeros(B, dtype=torch.int32, device=dev)
+    _, g = ops.scorer_edit_step(scorer, xx, m, v, lz, uz, torch.full((B,), 0.2, device=dev), step,
+                                torch.ones(B, dtype=torch.uint8, device=dev), not_nll=True, want_grad=True)
+    err = ((g.cpu().double() - g64).abs() / g64.abs().max(1, keepdim=True).values).flatten()
+    med, p99 = float(err.median()), float(err.kthvalue(int(0.99 * err.numel())).values)
+    print("scorer %s: gradient error / row max: median %.2e, 99 %% %.2e, max %.2e" % (scorer.gemm_format, med, p99, float(err.max())))
+    assert med < 5e-7 and p99 < 2e-5
+    scorer.check_range()          # nothing left the f16 range
+
+
+def test_scorer_f16_range_violation_is_reported(dev, scorer_sd_torch):
+    """f16x3 scorer: a latent beyond the f16 range (it would become inf - inf inside the split products) raises the
+    library's sticky flag, which ScorerWeights.check_range (st_scorer_status) turns into an error; the flag is reset by the
+    read, and the exact-f32 format takes the same input without complaint."""
+    from style_transfer_amd import ops, _lib
+    from style_transfer_amd.weights import ScorerWeights
+    sw = ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev, gemm_format="f16x3")
+    x = torch.rand(64, 256, device=dev) * 8
+    ops.scorer_embed(sw, x)
+    sw.check_range()
+    x[3, 7] = 1e6
+    ops.scorer_embed(sw, x)
+    with pytest.raises(_lib.StError, match="f16 range"):
+        sw.check_range()
+    sw.check_range()              # reset by the read
+    z = ops.scorer_embed(ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev, gemm_format="f32"), x)
+    assert torch.isfinite(z).all()

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--log-decodes", action="store_true")
     ap.add_argument("--ipd", default="12,6")
+    ap.add_argument("--scorer-format", default="f16x3")
     ap.add_argument("--single-max", type=int, default=None, help="AttackConfig.single_round_max_batch")
     ap.add_argument("--n", type=int, default=1000, help="sentences in all (the 1000 real ones tiled)")
     a = ap.parse_args()
@@ -29,7 +30,7 @@ def main():
     dev = torch.device("cuda", 0)
     ae = W.AEWeights(W.load_state_dict_file(os.path.join(GOLD, "surrogate_ae_yelp.safetensors")), dev)
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
-                             W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
+                             W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev, gemm_format=a.scorer_format)
     data = AttackSet.from_json([os.path.join(GOLD, "yelp", "neg10_pos10_test%d.json" % i) for i in (0, 1)], ae.vocab)
     if a.n != 1000:
         data = data.subset([i % 1000 for i in range(a.n)])

@@ -3,6 +3,7 @@
 // run:   kbench <rows> <generator splits, 0 = auto> <gemm_format 0|1> <kernel letters: g s f q o 2 u t>
 // -D switches (ablations, never in the library build): ST_ABL_NOSTORE (skip output stores), ST_NO_NT (temporal
 // stores), ST_TAIL_STAMPS (cycle stamps of the half-layer kernel's phases, printed after its timing)
+#define ST_RP_DEFINE_SWITCHES
 #include "st_rowpanel.h"
 
 #include <stdarg.h>
