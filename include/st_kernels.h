@@ -125,6 +125,11 @@ int st_scorer_status(int* out_of_range, int reset);
 #define ST_OPT_ADAMAX 3    /* m, u = max(0.999 u, |g| + 1e-8); x -= lr / (1 - 0.9^t) m / u          */
 #define ST_OPT_RMSPROP 4   /* v = 0.99 v + 0.01 g^2; x -= lr g / (sqrt(v) + 1e-8)                   */
 #define ST_OPT_ADAGRAD 5   /* s += g^2; x -= lr g / (sqrt(s) + 1e-10)                               */
+#define ST_OPT_NADAM 6     /* Adam with Nesterov momentum, momentum_decay 4e-3                     */
+#define ST_OPT_RADAM 7     /* rectified Adam (plain bias-corrected momentum while rho_t <= 5)      */
+#define ST_OPT_ADADELTA 8  /* rho 0.9, eps 1e-6; adam_v = square_avg, adam_m = acc_delta           */
+#define ST_OPT_ASGD 9      /* lambd 1e-4, alpha 0.75, t0 1e6 (the averaged iterate is not kept)    */
+#define ST_OPT_RPROP 10    /* etas (0.5, 1.2), step sizes [1e-6, 50]; adam_m = previous gradient, adam_v = step size */
 
 /* One edit iteration for B sentences (replaces get_contrastive_loss + `loss=-(loss); zero_grad();
  * loss.backward(); ori_optimizer.step()`, siamese_contrastive.py:796-810, with torch.optim.Adam

@@ -12,7 +12,8 @@ ST_ARGMAX_SPLITS = 4
 ST_NOALLOC_MAX_ROWS = 65536
 ST_F_NOT_NLL, ST_F_SIMPLEST, ST_F_JUST_USE_ONE = 1, 2, 4
 ST_F_OPT_SHIFT = 8
-ST_OPTIMIZERS = {"Adam": 0, "SGD": 1, "AdamW": 2, "Adamax": 3, "RMSprop": 4, "Adagrad": 5}   # torch.optim names
+ST_OPTIMIZERS = {"Adam": 0, "SGD": 1, "AdamW": 2, "Adamax": 3, "RMSprop": 4, "Adagrad": 5,
+                 "NAdam": 6, "RAdam": 7, "Adadelta": 8, "ASGD": 9, "Rprop": 10}   # torch.optim names (every first-order rule; LBFGS and SparseAdam are refused)
 ST_DEC_EARLY_EXIT = 1
 ST_DEC_NO_SCREEN = 2
 ST_PROF_OFF, ST_PROF_GENERATOR, ST_PROF_HALF_LAYER = 0, 1, 2

@@ -9,6 +9,7 @@
 // straight from L2, fragment-packed by st_pack_weight so each wave load is one coalesced 1 KiB read
 // (weights are 2.3 MB, read once per tile).
 #include "st_common.h"
+#include <stdlib.h>
 
 #define SC_LD 516        // activation row stride in floats (512 + 4; = 4 mod 64 -> conflict-free b128)
 #define SC_ROWS 32
@@ -159,10 +160,73 @@ __device__ __forceinline__ void update_row(const ScorerArgs& a, int b, f32x4 g) 
     v = v * 0.99f + (0.01f * g) * g;
 #pragma unroll
     for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-8f));
-  } else {  // ST_OPT_ADAGRAD
+  } else if (opt == ST_OPT_ADAGRAD) {
     v = v + g * g;
 #pragma unroll
     for (int q = 0; q < 4; ++q) x[q] -= lr * (g[q] / (sqrtf(v[q]) + 1e-10f));
+  } else if (opt == ST_OPT_NADAM) {
+    // torch.optim.NAdam (momentum_decay 4e-3): mu_t = 0.9 (1 - 0.5 * 0.96^(t * 0.004)), mu_product = prod_{i <= t} mu_i
+    const double mu = 0.9 * (1.0 - 0.5 * pow(0.96, (double)t * 0.004));
+    const double mu_next = 0.9 * (1.0 - 0.5 * pow(0.96, (double)(t + 1) * 0.004));
+    double mu_prod = 1.0;
+    for (int i = 1; i <= t; ++i) mu_prod *= 0.9 * (1.0 - 0.5 * pow(0.96, (double)i * 0.004));
+    const float bc2 = (float)(1.0 - pow(0.999, (double)t));
+    m = m + 0.1f * (g - m);
+    v = v * 0.999f + (0.001f * g) * g;
+    const float cg = (float)(-(double)lr * (1.0 - mu) / (1.0 - mu_prod));
+    const float cm = (float)(-(double)lr * mu_next / (1.0 - mu_prod * mu_next));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float den = sqrtf(v[q] / bc2) + 1e-8f;
+      x[q] += cg * (g[q] / den);
+      x[q] += cm * (m[q] / den);
+    }
+  } else if (opt == ST_OPT_RADAM) {
+    // torch.optim.RAdam: the variance rectification term switches on when rho_t > 5 (t >= 6 with beta2 = 0.999)
+    const double b2t = pow(0.999, (double)t);
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - b2t;
+    const double rho_inf = 2.0 / (1.0 - 0.999) - 1.0;
+    const double rho_t = rho_inf - 2.0 * (double)t * b2t / bc2;
+    m = m + 0.1f * (g - m);
+    v = v * 0.999f + (0.001f * g) * g;
+    const float bc1f = (float)bc1;
+    if (rho_t > 5.0) {
+      const float rect = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+      const float bc2s = (float)sqrt(bc2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] -= (m[q] / bc1f) * lr * (bc2s / (sqrtf(v[q]) + 1e-8f)) * rect;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] -= (m[q] / bc1f) * lr;
+    }
+  } else if (opt == ST_OPT_ADADELTA) {
+    // torch.optim.Adadelta (rho 0.9, eps 1e-6): v = square_avg, m = acc_delta
+    v = v * 0.9f + (0.1f * g) * g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float delta = sqrtf(m[q] + 1e-6f) / sqrtf(v[q] + 1e-6f) * g[q];
+      m[q] = m[q] * 0.9f + 0.1f * delta * delta;
+      x[q] -= lr * delta;
+    }
+  } else if (opt == ST_OPT_ASGD) {
+    // torch.optim.ASGD (lambd 1e-4, alpha 0.75, t0 1e6): eta_t = lr / (1 + lambd lr (t - 1))^alpha; the averaged iterate `ax`
+    // is never read by the edit loop
+    const float eta = (float)((double)lr / pow(1.0 + 1e-4 * (double)lr * (double)(t - 1), 0.75));
+    x = x * (1.0f - 1e-4f * eta);
+    x = x - eta * g;
+  } else {  // ST_OPT_RPROP (etas (0.5, 1.2), step sizes in [1e-6, 50]): m = previous gradient, v = step size (lr at the first step)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float ss = t == 1 ? lr : v[q];
+      const float sg = g[q] * m[q];
+      float gq = g[q];
+      if (sg > 0.0f) ss = fminf(ss * 1.2f, 50.0f);
+      else if (sg < 0.0f) { ss = fmaxf(ss * 0.5f, 1e-6f); gq = 0.0f; }
+      const float sgn = gq > 0.0f ? 1.0f : (gq < 0.0f ? -1.0f : 0.0f);
+      x[q] -= sgn * ss;
+      v[q] = ss;
+      m[q] = gq;
+    }
   }
   *(f32x4*)(a.adam_m + (size_t)b * 256 + lane * 4) = m;
   *(f32x4*)(a.adam_v + (size_t)b * 256 + lane * 4) = v;
@@ -355,6 +419,9 @@ __global__ __launch_bounds__(64 * SC_NW, 4) void scorer_kernel(ScorerArgs a) {
 //    st_scorer_status reports.
 // ================================================================================================
 #define SH_LO 256
+#ifndef SC16_RING
+#define SC16_RING 2
+#endif
 static __device__ int g_scorer_range_flag;
 
 template <int K, int N, bool FWD, int ACT, bool OUT_F32>
@@ -365,7 +432,7 @@ __device__ __forceinline__ void tile_linear16(float* Xs, const float* __restrict
   constexpr int DS = K / 32;            // double k-steps
   constexpr int NFT = N / 16 / SC_NW;   // 16-feature tiles per wave: tile t = wave + 8 i
   static_assert(NFT >= 1 && N % (16 * SC_NW) == 0 && K % 32 == 0, "layer shape");
-  constexpr int R = 2;                  // W ring depth in double steps
+  constexpr int R = SC16_RING;          // W ring depth in double steps
   static_assert(DS % R == 0, "ring");
   const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);
   const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, N * K * 4, 0x00020000);
@@ -459,8 +526,18 @@ __device__ __forceinline__ void tile_linear16(float* Xs, const float* __restrict
 
 #define SC16_LDS_BYTES ((SC_BUF + 32 * 32 * 2 + 32) * 4)
 
+// Two waves per SIMD = 256 registers per lane: one workgroup per CU.  With the 128-register budget of two workgroups per CU
+// (launch bound 4) the EDIT instantiation spilled (8 vector registers to scratch, 150 scalar registers to vector lanes) and
+// returned WRONG gradients on ~1 % of the rows - lanes 48..63 of one component of dP, only in the last row of a wave's row
+// loop, only in workgroups that started as the second one on a CU, different from run to run
+// (tools/check_scorer_determinism.py; the forward-only instantiation, which does not spill, never did).  Without spills the
+// kernel is bit-reproducible; the whole bench is 0.7 % slower than with two workgroups per CU, batch 256 is 4 % faster
+// (profiles/r03_scorer_f16x3.txt).  tests/test_gpu_kernels.py::test_scorer_edit_step_is_bit_reproducible guards it.
+#ifndef SC16_WAVES_PER_EU
+#define SC16_WAVES_PER_EU 2
+#endif
 template <bool EDIT>
-__global__ __launch_bounds__(64 * SC_NW, 4) void scorer16_kernel(ScorerArgs a) {
+__global__ __launch_bounds__(64 * SC_NW, SC16_WAVES_PER_EU) void scorer16_kernel(ScorerArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* buf = smem;                 // [32][SC_LD]: the one activation buffer
   float* cosv = smem + SC_BUF;       // [32][32]
@@ -620,7 +697,7 @@ extern "C" int st_scorer_edit_step(const StScorerWeights* w, float* latent, floa
   ST_CHECK_ARG((n_pos == 0 || like_z) && (n_neg == 0 || unlike_z), "NULL like_z/unlike_z");
   ST_CHECK_ARG((flags & ST_F_NOT_NLL) || n_pos > 0, "the NLL objective needs n_pos > 0");
   ST_CHECK_ARG(tau > 0.0f, "tau=%g", (double)tau);
-  ST_CHECK_ARG(((flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT) <= ST_OPT_ADAGRAD, "unknown optimizer code %d in flags",
+  ST_CHECK_ARG(((flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT) <= ST_OPT_RPROP, "unknown optimizer code %d in flags",
                (flags & ST_F_OPT_MASK) >> ST_F_OPT_SHIFT);
   if (!(flags & ST_F_SIMPLEST))
     ST_CHECK_ARG(w->p1_w && w->p1_wt && w->p1_b && w->p2_w && w->p2_wt && w->p2_b, "NULL Predictor weight pointer");

@@ -110,7 +110,8 @@ def test_attack_variants_match_reference(env, tag, flags, kw):
     assert n_div == 0, report
 
 
-@pytest.mark.parametrize("name,lr", [("SGD", 200.0), ("AdamW", 0.2), ("Adamax", 0.2), ("RMSprop", 0.05), ("Adagrad", 0.5)])
+@pytest.mark.parametrize("name,lr", [("SGD", 200.0), ("AdamW", 0.2), ("Adamax", 0.2), ("RMSprop", 0.05), ("Adagrad", 0.5),
+                                     ("NAdam", 0.2), ("RAdam", 0.2), ("Adadelta", 50.0), ("ASGD", 200.0), ("Rprop", 0.05)])
 def test_other_victim_optimizers_match_reference(env, name, lr):
     """--victim_optimizer other than Adam (siamese_contrastive.py:780 takes any torch.optim name): latents at every iteration,
     decodes and change counts against the reference's own run with that rule."""
@@ -412,6 +413,21 @@ def test_straggler_deferral_and_round_schedules_do_not_change_results(env):
     same = (a.n_iter == b.n_iter) & (a.iter_ids == b.iter_ids).all((1, 2)) & (a.init_ids == b.init_ids).all(1)
     print("one round vs two rounds: %d of 4096 sentences identical" % int(same.sum()))
     assert same.sum() >= 4096 - (0 if env["fmt"] == "f16x3" else 4)
+
+
+def test_the_same_batch_twice_gives_the_same_records(env):
+    """Run-to-run reproducibility of the whole path at a size with more workgroups than the chip holds at once: every
+    record of two runs of one batch of 16384 synthetic sentences must be bit-identical."""
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet
+    data = AttackSet.synthetic(16384, env["V"], "yelp", seed=6)
+    gidx = [i % 1000 for i in range(16384)]
+    cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False)
+    a = AttackRunner(env["ae"], env["scorer"], cfg, env["dev"]).run_batch(data, gidx)
+    b = AttackRunner(env["ae"], env["scorer"], cfg, env["dev"]).run_batch(data, gidx)
+    assert np.array_equal(a.final_latent, b.final_latent)
+    assert np.array_equal(a.n_iter, b.n_iter) and np.array_equal(a.changed, b.changed)
+    assert np.array_equal(a.iter_ids, b.iter_ids) and np.array_equal(a.init_ids, b.init_ids)
 
 
 def test_not_nll_with_unequal_counts_is_rejected_like_the_reference(env):

@@ -605,3 +605,31 @@ def test_scorer_f16_range_violation_is_reported(dev, scorer_sd_torch):
     sw.check_range()              # reset by the read
     z = ops.scorer_embed(ScorerWeights(scorer_sd_torch[0], scorer_sd_torch[1], dev, gemm_format="f32"), x)
     assert torch.isfinite(z).all()
+
+
+def test_scorer_edit_step_is_bit_reproducible(dev, scorer):
+    """The same edit steps from the same state must return the same bits, also with more workgroups than fit the chip at
+    once (1024 tiles of 32 sentences).  Guards a real failure: the first f16x3 scorer kernel was built for two workgroups per
+    CU, spilled registers, and returned different gradients from run to run on ~1 % of the rows (st_scorer.hip)."""
+    from style_transfer_amd import ops
+    torch.manual_seed(0)
+    B = 32768
+    x0 = torch.rand(B, 256, device=dev) * 8
+    lz = ops.scorer_embed(scorer, torch.rand(B * 10, 256, device=dev) * 8).view(B, 10, 256)
+    uz = ops.scorer_embed(scorer, torch.rand(B * 10, 256, device=dev) * 8).view(B, 10, 256)
+    like_again = torch.rand(B * 10, 256, device=dev) * 8
+    assert torch.equal(ops.scorer_embed(scorer, like_again), ops.scorer_embed(scorer, like_again))
+    outs = []
+    for rep in range(3):
+        x = x0.clone()
+        m, v = torch.zeros_like(x), torch.zeros_like(x)
+        step = torch.zeros(B, dtype=torch.int32, device=dev)
+        gs = []
+        for it in range(4):
+            _, g = ops.scorer_edit_step(scorer, x, m, v, lz, uz, torch.full((B,), 0.2, device=dev), step,
+                                        torch.ones(B, dtype=torch.uint8, device=dev), not_nll=True, want_grad=True)
+            gs.append(g)
+        outs.append((x, torch.stack(gs)))
+    for rep in (1, 2):
+        assert torch.equal(outs[0][1], outs[rep][1]), "gradients differ between identical runs"
+        assert torch.equal(outs[0][0], outs[rep][0]), "latents differ between identical runs"
