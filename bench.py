@@ -567,7 +567,9 @@ def main(argv=None):
         # read from inside the process): profiles/README.md gives the two commands; tools/traffic_from_pmc.py applies
         # the guide's gfx950 correction.  Only quoted for the configuration the passes were made on.
         traffic = traffic_src = alg_bytes = None
-        tfile = os.path.join(ROOT, "profiles", "r02_pmc_bench_half_layer_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r03_pmc_bench_half_layer_traffic.json")
+        bfile = os.path.join(ROOT, "profiles", "r03_pmc_phase_mfma_busy.json")
+        busy = None
         if split and gen_n.value > 0:
             # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
             alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
@@ -575,7 +577,10 @@ def main(argv=None):
                            and a.iters_per_decode == "12,6" and not a.log_decodes)
             if default_cfg and os.path.exists(tfile):
                 traffic = json.load(open(tfile))["bytes_per_launch"]
-                traffic_src = "profiles/r02_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"
+                traffic_src = "profiles/r03_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"
+            if default_cfg and os.path.exists(bfile):
+                busy = json.load(open(bfile))
+                busy["source"] = "profiles/r03_pmc_phase_mfma_busy.json (SQ counter pass of this command, tools/summarize_pmc.py)"
         fl = algorithmic_flops(ae, world * B * a.steps, tot[3], tot[4], tot[5], kp, kn, tot[:3])
         whole = fl["total"] / dt / 1e12
         # share of the algorithmic flops that run as AE matrix products (3 MFMA flops issued per flop in f16x3)
@@ -606,6 +611,8 @@ def main(argv=None):
                            "encoder_token_rows": tot[4],
                            "algorithmic_flops": fl, "algorithmic_tflops": whole, "peak": peak, "frac": whole / peak,
                            "mfma_issue_frac": whole * ((3 * ae_share + (1 - ae_share)) if split else 1) / peak,
+                           # counters cannot be read from inside the process: quoted from the committed counter pass of this command
+                           "mfma_busy": busy,
                            "note": "F_tok = 2[N(4d^2 + 2 d d_ff) + d V] + 2048 t per executed token-step (KV cache, cross-attention "
                                    "folded, no log-softmax) + encoder + scorer; token-steps counted on the device from the live "
                                    "counts; wall time includes every launch gap, host sync and the non-GEMM kernels"},

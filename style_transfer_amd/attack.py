@@ -60,6 +60,7 @@ class AttackConfig:
     # decode steps beats not decoding iterations that may be discarded: up to this many sentences ALL iterations are
     # decoded in one round (batch 256: 12.9 k -> 20.8 k sentences/s with this alone; results identical by construction)
     single_round_max_batch: int = 8192
+    merge_log_decodes_max_jobs: int = 600000   # decode jobs (241 KB of K/V cache each) up to which the log decodes join round 1
     defer_stragglers: bool = True  # see run_prepared: sentences whose decodes do not end are finished in an extra round
     count_units: bool = False
 
@@ -68,6 +69,17 @@ class AttackConfig:
         kw = {k: getattr(ns, k) for k in cls.__dataclass_fields__ if hasattr(ns, k)}
         kw.update(over)
         return cls(**kw)
+
+
+def sched_first(c, I, B):
+    """edit iterations decoded in the first round (AttackRunner.run_prepared's schedule)"""
+    if c.retext:
+        return 1
+    if isinstance(c.iters_per_decode, int):
+        return max(1, min(c.iters_per_decode, I))
+    if B <= c.single_round_max_batch:
+        return I
+    return max(1, min(int(c.iters_per_decode[0]), I))
 
 
 STRAGGLER_LEN = 32   # a decode job with no EOS/PAD among its first 32 tokens marks its sentence as a straggler
@@ -269,7 +281,12 @@ class AttackRunner:
         unlike_z = ops.scorer_embed(self.scorer, unlike_lat).view(B, kn, 256) if kn else None
         res = AttackResult(None, None, None, None)
         like_ids_dev = unlike_ids_dev = None
-        if c.log_decodes and (kp or kn):
+        # The Rec / Sim / Ref log lines need the decodes of the 1 + K+ + K- encoder latents (siamese_contrastive.py:713-732).
+        # They ride along in the FIRST decode round of the edit loop (one call of (rounds + 1 + K+ + K-) B jobs instead of
+        # two calls with a straggler tail each) unless that would not fit the K/V cache budget.
+        n_first = (sched_first(c, I, B) + 1 + kp + kn) * B
+        merge_log = c.log_decodes and (kp or kn) and not (c.retext or c.want_trace) and n_first <= c.merge_log_decodes_max_jobs
+        if c.log_decodes and (kp or kn) and not merge_log:
             ref_ids, _, _ = self.decode(lat_all[B:])
             like_ids_dev = ref_ids[:B * kp].view(B, kp, T) if kp else None
             unlike_ids_dev = ref_ids[B * kp:].view(B, kn, T) if kn else None
@@ -338,7 +355,14 @@ class AttackRunner:
                         tr["latent"].append(ori.detach().cpu().numpy().copy())
                         tr["grad"].append(grad.cpu().numpy())
                         tr["loss"].append(loss.cpu().numpy())
-                ids, gap, _ = self.decode(torch.cat(snaps, 0), want_gap=want_gap)
+                extra = lat_all[B:] if (merge_log and it0 == 0) else None
+                ids, gap, _ = self.decode(torch.cat(snaps + ([extra] if extra is not None else []), 0), want_gap=want_gap)
+                if extra is not None:
+                    ref_ids = ids[len(snaps) * n_live:]
+                    state["like_ids"] = ref_ids[:B * kp].view(B, kp, T) if kp else None
+                    state["unlike_ids"] = ref_ids[B * kp:].view(B, kn, T) if kn else None
+                    ids = ids[:len(snaps) * n_live]
+                    gap = gap[:len(snaps) * n_live] if gap is not None else None
                 ids = ids.view(len(snaps), n_live, T)
                 gap = gap.view(len(snaps), n_live, T) if gap is not None else None
                 k0 = 0
@@ -396,6 +420,8 @@ class AttackRunner:
             rounds(~state["deferred"], it_done, sched[1:])
             rounds(state["deferred"], it_done, [I])
         init_ids, acc_ids, init_gap, n_units = state["init_ids"], state["acc_ids"], state["init_gap"], state["n_units"]
+        if merge_log:
+            like_ids_dev, unlike_ids_dev = state.get("like_ids"), state.get("unlike_ids")
         tm["deferred_sentences"] = 0 if state["deferred"] is None else int(state["deferred"].sum().item())
         if not c.count_units:
             n_units = int(was_active.sum().item())

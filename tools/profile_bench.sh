@@ -17,7 +17,7 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "fetch done"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O -o write -- python3 bench.py --no-cpu-baseline --no-side-runs --steps 1 --warmup 0 > $O/write.json 2> $O/write.err
 echo "write done"
-python3 tools/summarize_pmc.py $O/sq_counter_collection.csv > $O/sq_per_kernel.csv
+python3 tools/summarize_pmc.py $O/sq_counter_collection.csv $O/phase_mfma_busy.json > $O/sq_per_kernel.csv
 tail -3 $O/sq_per_kernel.csv | cut -d, -f1-4
 python3 tools/traffic_from_pmc.py $O/fetch_counter_collection.csv $O/write_counter_collection.csv rp_layer_tail16_kernel > $O/traffic.json
 rm -f $O/*_counter_collection.csv $O/*_kernel_trace.csv   # (large; the summaries are what is kept)

@@ -43,6 +43,14 @@ def main():
     for g in ("set-up", "edit loop", "whole run"):
         v = groups[g]
         w.writerow(["== " + g, g, "", "%.1f" % busy(v)] + ["%.6g" % v.get(c, 0.0) for c in names])
+    if len(sys.argv) > 2:      # second argument: a JSON file for bench.py (whole_step.mfma_busy_pct)
+        import json
+        tot = groups["whole run"].get("GRBM_GUI_ACTIVE", 0.0) or 1.0
+        json.dump({"mfma_busy_pct": {g: round(busy(groups[g]), 2) for g in ("set-up", "edit loop", "whole run")},
+                   "gpu_active_share_pct": {g: round(100.0 * groups[g].get("GRBM_GUI_ACTIVE", 0.0) / tot, 2) for g in ("set-up", "edit loop")},
+                   "definition": "sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum GRBM_GUI_ACTIVE / 8) over the kernels of the phase; "
+                                 "one rocprofv3 --pmc pass over one step of the default bench (tools/profile_bench.sh)"},
+                  open(sys.argv[2], "w"), indent=1)
 
 
 if __name__ == "__main__":
