@@ -93,6 +93,8 @@ def parse_args(argv=None):
     ap.add_argument("--gemm-format", default="f16x3", choices=["f16x3", "f32"],
                     help="operand format of the AE weight GEMMs: 3-product f16 split (f32-grade results) or exact f32 MFMA")
     ap.add_argument("--scorer-format", default=None, choices=["f16x3", "f32"], help="operand format of the style scorer (default: --gemm-format)")
+    ap.add_argument("--no-l0-table", action="store_true", help="A/B: project the first decoder layer's q | k | v per step instead of "
+                    "reading the (token, position) table")
     ap.add_argument("--config", default="attack", choices=["attack", "simloss"],
                     help="attack: the headline workload (BASELINE configs 1-4); simloss: BASELINE config 5, one contrastive constraint-loss "
                          "step (11 views, forward + backward) with B = --simloss-batch GLOBAL in-batch negatives, rows sharded over the GPUs")
@@ -338,7 +340,7 @@ def main(argv=None):
 
     # yelp shape: V = 9339; amazon shape: V = 19724 with its own surrogate AE (no amazon weights ship at all)
     ae_file = os.path.join(GOLD, "surrogate_ae_%s.safetensors" % a.shape)
-    ae = W.AEWeights(W.load_state_dict_file(ae_file), dev, gemm_format=a.gemm_format)
+    ae = W.AEWeights(W.load_state_dict_file(ae_file), dev, gemm_format=a.gemm_format, l0_table=not a.no_l0_table)
     scorer = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
                              W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev,
                              gemm_format=a.scorer_format or a.gemm_format)

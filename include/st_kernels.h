@@ -173,7 +173,22 @@ typedef struct StDecoderWeights {
   const float* gen_w_norm;             /* [V] ||generator.proj.weight[v]||_2, each rounded UP, or NULL: with it the screened
                                           argmax bounds every column by its own norm instead of gen_w_maxnorm           */
   StDecLayer layer[ST_MAX_LAYERS];
+  const float* l0_table;               /* NULL, or the table st_decode_build_l0_table filled: [vocab][l0_table_len][768] f32.
+                                          The first decoder layer's self-attention input is LayerNorm(emb[token] * 16 + pe[pos]):
+                                          its q | k | v depend on (token, position) alone, not on the sentence, so they are
+                                          computed once per checkpoint; decode steps then skip that layer's QKV projection and
+                                          its K/V cache and read the rows of the tokens already emitted (f16x3 format)        */
+  int32_t l0_table_len;                /* positions per token in l0_table (>= max_len - 1 of every decode call)            */
+  int32_t reserved1;
 } StDecoderWeights;
+
+/* Bytes of the first-layer q | k | v table for `positions` decode positions, and its construction: rows = vocab * positions
+ * through the layer's own LayerNorm + stacked projection kernel (the values a decode step would compute, bit for bit).
+ * scratch: vocab * positions * 1024 bytes (the embedded inputs).  No counterpart in the reference (model.py:191-196 recomputes
+ * them for every sentence and every step).                                                                                */
+size_t st_decode_l0_table_bytes(const StDecoderWeights* w, int positions);
+int st_decode_build_l0_table(const StDecoderWeights* w, int positions, float* table, void* scratch, size_t scratch_bytes,
+                             void* stream);
 
 /* bytes of device workspace st_decode_greedy needs for B sentences */
 size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len);
@@ -182,6 +197,7 @@ size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len);
 #define ST_DEC_EARLY_EXIT 1   /* stop a sentence at its first EOS/PAD token (output-equivalent:
                                  data.py:43-52 truncates there); off = the reference's fixed
                                  max_len-1 steps                                                 */
+#define ST_DEC_NO_L0_TABLE 4  /* ignore StDecoderWeights.l0_table: project the first layer's q | k | v per step (tests, A/B) */
 #define ST_DEC_NO_SCREEN 2    /* f16x3 format: always run the 3-product generator (no one-product
                                  screening pass; see gen_w_maxnorm)                              */
 

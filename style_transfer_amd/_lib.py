@@ -16,10 +16,11 @@ ST_OPTIMIZERS = {"Adam": 0, "SGD": 1, "AdamW": 2, "Adamax": 3, "RMSprop": 4, "Ad
                  "NAdam": 6, "RAdam": 7, "Adadelta": 8, "ASGD": 9, "Rprop": 10}   # torch.optim names (every first-order rule; LBFGS and SparseAdam are refused)
 ST_DEC_EARLY_EXIT = 1
 ST_DEC_NO_SCREEN = 2
+ST_DEC_NO_L0_TABLE = 4
 ST_PROF_OFF, ST_PROF_GENERATOR, ST_PROF_HALF_LAYER = 0, 1, 2
 ST_GEMM_F32, ST_GEMM_F16X3 = 0, 1
 GEMM_FORMATS = {"f32": ST_GEMM_F32, "f16x3": ST_GEMM_F16X3}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -41,7 +42,8 @@ class StDecoderWeights(C.Structure):
                 ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
                 ("gemm_format", C.c_int32), ("gen_w_maxnorm", C.c_float),
                 ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp), ("gen_w", fp), ("gen_b", fp), ("gen_w_norm", fp),
-                ("layer", StDecLayer * ST_MAX_LAYERS)]
+                ("layer", StDecLayer * ST_MAX_LAYERS),
+                ("l0_table", fp), ("l0_table_len", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class StEncLayer(C.Structure):
@@ -89,6 +91,8 @@ EXPORTS = {
     "st_scorer_embed": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, C.c_int, C.c_int, fp]),
     "st_scorer_edit_step": (C.c_int, [C.POINTER(StScorerWeights), fp, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp, fp,
                                       C.c_int, C.c_float, C.c_int, fp, fp, fp, fp]),
+    "st_decode_l0_table_bytes": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int]),
+    "st_decode_build_l0_table": (C.c_int, [C.POINTER(StDecoderWeights), C.c_int, fp, fp, C.c_size_t, fp]),
     "st_decode_workspace_bytes": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int, C.c_int]),
     "st_decode_greedy": (C.c_int, [C.POINTER(StDecoderWeights), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, fp, fp, fp, C.c_size_t, C.POINTER(C.c_int), fp]),

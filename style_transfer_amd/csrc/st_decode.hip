@@ -16,7 +16,7 @@ void st_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 6; }
+extern "C" int st_abi_version(void) { return 7; }
 
 // ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
 #include <vector>
@@ -230,6 +230,125 @@ __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restric
   for (int j = 0; j < 16; ++j)
     if (j <= pos) o4 += (sc[j] * inv) * vr[j];
   *(f32x4*)(out + (size_t)r * 256 + lane * 4) = o4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// First decoder layer with the (token, position) table (StDecoderWeights.l0_table): the layer's q | k | v rows depend
+// on (token, position) only, so a decode step reads them from the table instead of projecting them and caching K / V per
+// job.  tok(j) = BOS for j = 0, else the token the job emitted at step j - 1.  Same arithmetic as attn_step16_kernel /
+// attn_step_kernel on the same values: identical outputs.  The table is shared by all jobs, so frequent (token, position)
+// rows are served from L2 / Infinity Cache instead of HBM.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l0_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe, int vocab,
+                                                       int positions, float* __restrict__ x) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long)vocab * positions) return;
+  const int lane = threadIdx.x & 63;
+  const int tok = (int)(r / positions), pos = (int)(r % positions);
+  const f32x4 e = *(const f32x4*)(emb + (size_t)tok * 256 + lane * 4);
+  const f32x4 p = *(const f32x4*)(pe + (size_t)pos * 256 + lane * 4);
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;   // exactly embed_kernel's expression
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void attn_step16_tab_kernel(const float* __restrict__ tab, int tab_len,
+                                                              const int32_t* __restrict__ ys, int T, int bos, int vocab,
+                                                              const int* __restrict__ idx, const int* __restrict__ n_dev,
+                                                              int pos, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= *n_dev) return;
+  const long s = idx[r];
+  // lane j holds the token of key position j (j <= pos < 16)
+  int tokj = bos;
+  if (lane >= 1 && lane <= pos) tokj = ys[(size_t)s * T + lane - 1];
+  tokj = min(max(tokj, 0), vocab - 1);
+  f32x4 kr[16], vr[16];
+  f32x4 qv;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j <= pos) {  // uniform
+      const int t = __builtin_amdgcn_readlane(tokj, j);
+      const float* row = tab + ((size_t)t * tab_len + j) * 768 + lane * 4;
+      kr[j] = *(const f32x4*)(row + 256);
+      vr[j] = *(const f32x4*)(row + 512);
+      if (j == pos) qv = *(const f32x4*)row;
+    }
+  float sc[16];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sc[j] = -INFINITY;
+    if (j <= pos) {
+      const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
+      sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
+      m = fmaxf(m, sc[j]);
+    }
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j <= pos) {
+      sc[j] = FAST ? __expf(sc[j] - m) : expf(sc[j] - m);
+      sum += sc[j];
+    }
+  const float inv = 1.0f / sum;
+  f32x4 o4 = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j <= pos) o4 += (sc[j] * inv) * vr[j];
+  *(f32x4*)(out + (size_t)r * 256 + lane * 4) = o4;
+}
+
+// general form (16 <= pos < 64): attn_step_kernel with the K / V rows of the emitted tokens
+__global__ __launch_bounds__(256) void attn_step_tab_kernel(const float* __restrict__ tab, int tab_len,
+                                                            const int32_t* __restrict__ ys, int T, int bos, int vocab,
+                                                            const int* __restrict__ idx, const int* __restrict__ n_dev,
+                                                            int pos, float* __restrict__ out) {
+  __shared__ __align__(16) float qs[256];
+  __shared__ int toks[64];
+  const int r = blockIdx.x;
+  if (r >= *n_dev) return;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const long s = idx[r];
+  if (tid < 64) {
+    int t = bos;
+    if (tid >= 1 && tid <= pos) t = ys[(size_t)s * T + tid - 1];
+    toks[tid] = min(max(t, 0), vocab - 1);
+  }
+  __syncthreads();
+  qs[tid] = tab[((size_t)toks[pos] * tab_len + pos) * 768 + tid];
+  __syncthreads();
+  float sc = -INFINITY;
+  if (lane <= pos) {
+    const float* kr = tab + ((size_t)toks[lane] * tab_len + lane) * 768 + 256 + h * 64;
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4 kv = *(const f32x4*)(kr + d);
+      const f32x4 qv = *(const f32x4*)(qs + h * 64 + d);
+      acc = fmaf(qv.x, kv.x, acc);
+      acc = fmaf(qv.y, kv.y, acc);
+      acc = fmaf(qv.z, kv.z, acc);
+      acc = fmaf(qv.w, kv.w, acc);
+    }
+    sc = acc * 0.125f;  // / sqrt(d_k)
+  }
+  const float m = wave_max(sc);
+  const float e = lane <= pos ? expf(sc - m) : 0.0f;
+  const float p = e / wave_sum(e);
+  auto vrow = [&](int j) -> float { return tab[((size_t)toks[j] * tab_len + j) * 768 + 512 + h * 64 + lane]; };
+  float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;   // four independent chains, as attn_step_kernel
+  int j = 0;
+  for (; j + 3 <= pos; j += 4) {
+    const float v0 = vrow(j), v1 = vrow(j + 1), v2 = vrow(j + 2), v3 = vrow(j + 3);
+    o0 = fmaf(__shfl(p, j, 64), v0, o0);
+    o1 = fmaf(__shfl(p, j + 1, 64), v1, o1);
+    o2 = fmaf(__shfl(p, j + 2, 64), v2, o2);
+    o3 = fmaf(__shfl(p, j + 3, 64), v3, o3);
+  }
+  for (; j <= pos; ++j) o0 = fmaf(__shfl(p, j, 64), vrow(j), o0);
+  out[(size_t)r * 256 + h * 64 + lane] = (o0 + o1) + (o2 + o3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,6 +791,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   // attn_step16_kernel keeps 12 independent rows per CU in flight all the time.
   const bool fuse_qkv_attn = w->gemm_format == ST_GEMM_F16X3 && rp_dec_fused && kv_stride % 4 == 0 && ((size_t)ws.kv & 15) == 0;
   const int fuse_min_rows = 1;
+  const bool use_tab = w->l0_table != nullptr && w->l0_table_len >= T && w->gemm_format == ST_GEMM_F16X3 && !(options & ST_DEC_NO_L0_TABLE);
   int n_bound = B;
   int cur = 0;
   int steps = 0;
@@ -688,6 +808,16 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       const StDecLayer& y = w->layer[l];
       float* kb = ws.kv + (size_t)(l * 2 + 0) * T * 256;
       float* vb = ws.kv + (size_t)(l * 2 + 1) * T * 256;
+      if (l == 0 && use_tab) {
+        // first layer: q | k | v of (token, position) from the table; no projection, no K / V cache rows
+        if (pos < 16)
+          hipLaunchKernelGGL(attn_step16_tab_kernel<true>, dim3((n_bound + 3) / 4), dim3(256), 0, st, w->l0_table, w->l0_table_len,
+                             out_ids, T, bos, w->vocab, idx, n_dev, pos, ws.att);
+        else
+          hipLaunchKernelGGL(attn_step_tab_kernel, dim3(n_bound), dim3(256), 0, st, w->l0_table, w->l0_table_len, out_ids, T, bos,
+                             w->vocab, idx, n_dev, pos, ws.att);
+        ST_LAUNCH_CHECK();
+      } else {
       GemmArgs g = {};
       g.fmt = w->gemm_format; g.range_flag = ws.cnt + 3;
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
@@ -712,6 +842,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
         hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
                            ws.att);
       ST_LAUNCH_CHECK();
+      }
       }
       OFArgs of = {};
       of.fmt = w->gemm_format; of.range_flag = ws.cnt + 3;
@@ -906,5 +1037,51 @@ extern "C" int st_pack_weight(const float* W, int N, int K, int gemm_format, flo
                        out);
   }
   ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+extern "C" size_t st_decode_l0_table_bytes(const StDecoderWeights* w, int positions) {
+  if (!w || positions <= 0 || w->vocab <= 0) return 0;
+  return (size_t)w->vocab * positions * 768 * 4;
+}
+
+extern "C" int st_decode_build_l0_table(const StDecoderWeights* w, int positions, float* table, void* scratch,
+                                        size_t scratch_bytes, void* stream) {
+  ST_TRY(check_weights(w, positions + 1));
+  ST_CHECK_ARG(table && scratch, "NULL buffer");
+  ST_CHECK_ARG(w->gemm_format == ST_GEMM_F16X3, "the first-layer table is used by the f16x3 format only");
+  const long rows = (long)w->vocab * positions;
+  ST_CHECK_ARG(rows < (1L << 31), "vocab * positions = %ld rows: too large", rows);
+  ST_CHECK_ARG(scratch_bytes >= (size_t)rows * 1024, "scratch too small: need %zu bytes", (size_t)rows * 1024);
+  hipStream_t st = (hipStream_t)stream;
+  float* x = (float*)scratch;
+  int* flag = nullptr;
+  ST_HIP(hipMalloc(&flag, sizeof(int)));
+  ST_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+  hipLaunchKernelGGL(l0_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, w->emb, w->pe, w->vocab, positions, x);
+  ST_LAUNCH_CHECK();
+  // the decode step's own kernel (rp_lin16_kernel, LayerNorm prologue, bias in the accumulator): same values bit for bit
+  const StDecLayer& y = w->layer[0];
+  int rc = ST_OK;
+  for (long r0 = 0; r0 < rows && rc == ST_OK; r0 += 1 << 20) {
+    const int n = (int)((rows - r0 < (1L << 20)) ? rows - r0 : (1L << 20));
+    GemmArgs g = {};
+    g.fmt = w->gemm_format; g.range_flag = flag;
+    g.X = x + (size_t)r0 * 256; g.n_host = n; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
+    g.out = table + (size_t)r0 * 768; g.ldo = 768;
+    rc = launch_rp_lin_pipelined<EPI_BIAS>(g, n, 3, st);
+  }
+  int bad = 0;
+  if (rc == ST_OK) {
+    hipError_t e = hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = ST_EHIP;
+  }
+  (void)hipFree(flag);
+  if (rc != ST_OK) return rc;
+  if (bad) {
+    st_set_error("st_decode_build_l0_table: an activation left the f16 range; pack the weights with ST_GEMM_F32");
+    return ST_ERANGE;
+  }
   return ST_OK;
 }

@@ -46,7 +46,7 @@ class DecodeWorkspace:
 
 
 def greedy_decode(ae, latent, max_len=60, start_id=2, eos=3, pad=0, early_exit=True, sync_every=1,
-                  want_gap=False, ws: DecodeWorkspace = None, screen=True):
+                  want_gap=False, ws: DecodeWorkspace = None, screen=True, l0_table=True):
     """-> (ids [B,max_len-1] int32, gap or None, steps_run).
     screen=False (or want_gap=True) forces the full 3-product generator of the f16x3 format on every row."""
     _f32(latent)
@@ -62,7 +62,8 @@ def greedy_decode(ae, latent, max_len=60, start_id=2, eos=3, pad=0, early_exit=T
     buf = ws.get(need)
     steps = C.c_int(0)
     check(lib().st_decode_greedy(C.byref(ae.dec), latent.data_ptr(), B, max_len, start_id, eos, pad,
-                                 (_lib.ST_DEC_EARLY_EXIT if early_exit else 0) | (0 if screen else _lib.ST_DEC_NO_SCREEN),
+                                 (_lib.ST_DEC_EARLY_EXIT if early_exit else 0) | (0 if screen else _lib.ST_DEC_NO_SCREEN) |
+                                 (0 if l0_table else _lib.ST_DEC_NO_L0_TABLE),
                                  sync_every, ids.data_ptr(), _p(gap),
                                  buf.data_ptr(), buf.numel(), C.byref(steps), _stream()), "st_decode_greedy")
     return ids, gap, steps.value

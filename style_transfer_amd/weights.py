@@ -67,7 +67,8 @@ class AEWeights(_Packed):
     gemm_format: "f16x3" (default: 3-product f16 split on the f16 MFMA, f32-grade results) or "f32"
     (exact f32 MFMA, ~3x slower)."""
 
-    def __init__(self, sd: dict, device, max_len: int = 60, gemm_format: str = "f16x3"):
+    def __init__(self, sd: dict, device, max_len: int = 60, gemm_format: str = "f16x3", l0_table: bool = True,
+                 l0_table_max_bytes: int = 8 << 30):
         super().__init__(device, gemm_format)
         if gemm_format not in _lib.GEMM_FORMATS:
             raise ValueError("gemm_format %r: expected one of %s" % (gemm_format, sorted(_lib.GEMM_FORMATS)))
@@ -109,6 +110,23 @@ class AEWeights(_Packed):
             y.ln2_a, y.ln2_b = self.dev(sd[p + "sublayer.2.norm.a_2"]), self.dev(sd[p + "sublayer.2.norm.b_2"])
             y.w1, y.b1 = self.packed(sd[p + "feed_forward.w_1.weight"]), self.dev(sd[p + "feed_forward.w_1.bias"])
             y.w2, y.b2 = self.packed(sd[p + "feed_forward.w_2.weight"]), self.dev(sd[p + "feed_forward.w_2.bias"])
+        # first decoder layer: q | k | v per (token, position), computed once (st_kernels.h: l0_table); skipped for
+        # vocabularies whose table would exceed l0_table_max_bytes
+        self.dec.l0_table, self.dec.l0_table_len = None, 0
+        if gemm_format == "f16x3" and l0_table:
+            T = max_len - 1
+            L = _lib.lib()
+            import ctypes as C
+            nbytes = L.st_decode_l0_table_bytes(C.byref(self.dec), T)
+            if 0 < nbytes <= l0_table_max_bytes:
+                tab = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+                scratch = torch.empty(self.vocab * T * 256, dtype=torch.float32, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(L.st_decode_build_l0_table(C.byref(self.dec), T, tab.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                                          torch.cuda.current_stream().cuda_stream), "st_decode_build_l0_table")
+                del scratch
+                self._keep.append(tab)
+                self.dec.l0_table, self.dec.l0_table_len = tab.data_ptr(), T
         self.enc = _lib.StEncoderWeights()
         s = self.enc
         n_enc = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))

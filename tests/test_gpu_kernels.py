@@ -633,3 +633,25 @@ def test_scorer_edit_step_is_bit_reproducible(dev, scorer):
     for rep in (1, 2):
         assert torch.equal(outs[0][1], outs[rep][1]), "gradients differ between identical runs"
         assert torch.equal(outs[0][0], outs[rep][0]), "latents differ between identical runs"
+
+
+def test_first_layer_table_gives_the_same_decodes(dev, ae_sd_torch, gold_notnll):
+    """The first decoder layer's q | k | v depend on (token, position) only; with StDecoderWeights.l0_table the decode steps
+    read them from a table built once per checkpoint instead of projecting them and caching K / V per job.  Same kernel,
+    same values: the decoded ids must be identical, with early exit and with the reference's fixed 59 steps (prefixes beyond
+    16 keys take the general attention kernel)."""
+    from style_transfer_amd import ops
+    from style_transfer_amd.weights import AEWeights
+    ae = AEWeights(ae_sd_torch, dev, gemm_format="f16x3")
+    assert ae.dec.l0_table and ae.dec.l0_table_len == 59
+    rng = np.random.default_rng(8)
+    base = gold_notnll["latent"].reshape(-1, 256)[:1152]
+    lat = torch.from_numpy(np.concatenate([base, base + rng.standard_normal(base.shape).astype(np.float32) * 0.3]).astype(np.float32)).to(dev)
+    for early in (True, False):
+        a, _, sa = ops.greedy_decode(ae, lat, early_exit=early, l0_table=True)
+        b, _, sb = ops.greedy_decode(ae, lat, early_exit=early, l0_table=False)
+        assert sa == sb and torch.equal(a, b), early
+    small = lat[:40].contiguous()            # a handful of rows: the small-grid kernel forms
+    a, ga, _ = ops.greedy_decode(ae, small, want_gap=True, l0_table=True)
+    b, gb, _ = ops.greedy_decode(ae, small, want_gap=True, l0_table=False)
+    assert torch.equal(a, b) and torch.equal(ga, gb)
