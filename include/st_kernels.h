@@ -282,12 +282,22 @@ typedef struct StEncLayer {
 } StEncLayer;
 typedef struct StEncoderWeights {
   int32_t d_model, n_heads, d_ff, n_layers, vocab, pe_rows;
-  int32_t gemm_format, reserved0;      /* ST_GEMM_*: format of wqkv / wo / w1 / w2 (all PACKED)  */
+  int32_t gemm_format;                 /* ST_GEMM_*: format of wqkv / wo / w1 / w2 (all PACKED)  */
+  int32_t l0_table_len;                /* positions per token in l0_table                        */
   const float* emb;                    /* src_embed.0.lut.weight [V,256] (shared with tgt)      */
   const float* pe;                     /* src_embed.1.pe                                        */
   const float *lnf_a, *lnf_b;          /* encoder.norm                                          */
   StEncLayer layer[ST_MAX_LAYERS];
+  const float* l0_table;               /* NULL, or st_encode_build_l0_table's [vocab][l0_table_len][768]: q | k | v of the first
+                                          encoder layer per (token, position) - its input LayerNorm(emb[token] * 16 + pe[pos])
+                                          does not depend on the sentence.  With it (f16x3 format, every sentence no longer than
+                                          l0_table_len) the first layer runs no projection: identical latents                 */
 } StEncoderWeights;
+/* the encoder's first-layer table: see StDecoderWeights.l0_table / st_decode_build_l0_table (same construction, scratch =
+ * vocab * positions * 1024 bytes).  No counterpart in the reference.                                                        */
+size_t st_encode_l0_table_bytes(const StEncoderWeights* w, int positions);
+int st_encode_build_l0_table(const StEncoderWeights* w, int positions, float* table, void* scratch, size_t scratch_bytes,
+                             void* stream);
 size_t st_encode_workspace_bytes(const StEncoderWeights* w, int n_rows, int n_sent);
 int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens, const int32_t* tok_pos,
                      const int32_t* sent_off, int n_rows, int n_sent, int max_sent_len, float* latent,

@@ -54,9 +54,9 @@ class StEncLayer(C.Structure):
 class StEncoderWeights(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_heads", C.c_int32), ("d_ff", C.c_int32),
                 ("n_layers", C.c_int32), ("vocab", C.c_int32), ("pe_rows", C.c_int32),
-                ("gemm_format", C.c_int32), ("reserved0", C.c_int32),
+                ("gemm_format", C.c_int32), ("l0_table_len", C.c_int32),
                 ("emb", fp), ("pe", fp), ("lnf_a", fp), ("lnf_b", fp),
-                ("layer", StEncLayer * ST_MAX_LAYERS)]
+                ("layer", StEncLayer * ST_MAX_LAYERS), ("l0_table", fp)]
 
 
 class StAeLayer(C.Structure):
@@ -104,6 +104,8 @@ EXPORTS = {
     "st_simloss_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "st_simloss_fwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, C.c_size_t, fp]),
     "st_simloss_bwd": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp, fp, fp, fp, C.c_size_t, fp]),
+    "st_encode_l0_table_bytes": (C.c_size_t, [C.POINTER(StEncoderWeights), C.c_int]),
+    "st_encode_build_l0_table": (C.c_int, [C.POINTER(StEncoderWeights), C.c_int, fp, fp, C.c_size_t, fp]),
     "st_encode_workspace_bytes": (C.c_size_t, [C.POINTER(StEncoderWeights), C.c_int, C.c_int]),
     "st_scorer_train_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "st_scorer_train_step": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, fp, C.c_uint64,

@@ -459,6 +459,164 @@ __global__ __launch_bounds__(512) void enc_qkv_attn16_kernel(EqaArgs a) {
   if (bad && a.range_flag) *a.range_flag = 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// First encoder layer with the (token, position) table (StEncoderWeights.l0_table): the layer's input is
+// LayerNorm(emb[token] * 16 + pe[pos]), so its q | k | v rows depend on (token, position) only and are computed once per
+// checkpoint (st_encode_build_l0_table, with rp_lin16_kernel: the values enc_qkv_attn16_kernel's projection produces, bit
+// for bit).  enc_tab_attn16_kernel is enc_qkv_attn16_kernel with the projection replaced by a gather: per head the
+// window's q | k | v rows travel from the table into the SAME split-f16 head buffers, and the attention block below is
+// that kernel's, instruction for instruction: identical latents.  No panel, no LayerNorm, no MFMA projection; 56 KiB of
+// LDS, two workgroups per CU; the table is shared by all sentences (frequent rows come from L2 / Infinity Cache).
+// ------------------------------------------------------------------------------------------------
+#define ETA_LDS ((3 * 64 * EQA_LD + 2 * 64) * 4)
+struct EtaArgs {
+  const float* tab;        // [vocab][tab_len][768]
+  int tab_len, vocab;
+  const int32_t* tokens;   // [R]
+  const int32_t* tok_pos;  // [R]
+  const int32_t* off;      // [n_sent + 1]
+  const int32_t* first_sent;
+  float* att;              // [R,256]
+  int R, n_sent, n_win;
+};
+__global__ __launch_bounds__(512, 4) void enc_tab_attn16_kernel(EtaArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* Qs = smem;                      // [64 rows][EQA_LD] q of the current head, f16 hi | lo
+  float* Ks = Qs + 64 * EQA_LD;          // [64 rows][EQA_LD] k
+  float* Vt = Ks + 64 * EQA_LD;          // [64 dims][EQA_LD] v TRANSPOSED
+  int* slist = (int*)(Vt + 64 * EQA_LD);
+  int* scount = slist + 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  // gather role of this thread: panel row tid >> 3, six float4 of the head's 48 (q: 0..15, k: 16..31, v: 32..47)
+  const int grow = tid >> 3, gpart = tid & 7;
+  for (int p = blockIdx.x; p < a.n_win; p += gridDim.x) {
+    const int s_lo = a.first_sent[p], s_hi = a.first_sent[p + 1];
+    if (s_lo >= s_hi) continue;  // (uniform)
+    const int r0 = a.off[s_lo];
+    int nr = a.off[s_hi] - r0;
+    if (nr <= 0 || nr > 64 || r0 < 0 || r0 + nr > a.R || s_lo < 0 || s_hi > a.n_sent) continue;  // (bad offsets are flagged elsewhere)
+    if (tid == 0) *scount = 0;
+    const int rr = r0 + min(grow, nr - 1);
+    const int tk = min(max(a.tokens[rr], 0), a.vocab - 1);
+    const int ps = min(max(a.tok_pos[rr], 0), a.tab_len - 1);
+    const float* trow = a.tab + ((size_t)tk * a.tab_len + ps) * 768;
+    __syncthreads();  // the previous window's attention is done (head buffers, slist), scount is reset
+    for (int s = s_lo + tid; s < s_hi; s += 512) {
+      const int b = a.off[s] - r0, e = a.off[s + 1] - r0;
+      if (e > b && e <= 64) slist[atomicAdd(scount, 1)] = b | ((e - b) << 8);
+    }
+    f32x4 tv[6];
+    auto tload = [&](int h) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int c4 = gpart * 6 + i;
+        tv[i] = *(const f32x4*)(trow + 256 * (c4 >> 4) + 64 * h + 4 * (c4 & 15));
+      }
+    };
+    tload(0);
+    for (int h = 0; h < 4; ++h) {
+      if (h > 0) __syncthreads();  // every wave is done with the previous head's attention
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int c4 = gpart * 6 + i;
+        const int d0 = 4 * (c4 & 15);
+        h4 hi, lo;
+        split_f16(tv[i], hi, lo);
+        if ((c4 >> 4) < 2) {
+          _Float16* dst = (_Float16*)(((c4 >> 4) ? Ks : Qs) + grow * EQA_LD) + d0;
+          *(h4*)dst = hi;
+          *(h4*)(dst + 64) = lo;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            _Float16* dst = (_Float16*)(Vt + (d0 + j) * EQA_LD) + grow;
+            dst[0] = hi[j];
+            dst[64] = lo[j];
+          }
+        }
+      }
+      if (h < 3) tload(h + 1);  // in flight during this head's attention
+      __syncthreads();  // q | k | v^T of head h complete
+      {
+        const int ns = *scount;
+        for (int si = wave; si < ns; si += 8) {
+          const int ent = slist[si], first = ent & 255, len = ent >> 8;  // (wave-uniform)
+          const int row = min(first + r16, 63);
+          const float* qb = Qs + row * EQA_LD + 4 * g;
+          const h8 qh0 = as_h8(*(const f32x4*)(qb)), qh1 = as_h8(*(const f32x4*)(qb + 16));
+          const h8 ql0 = as_h8(*(const f32x4*)(qb + 32)), ql1 = as_h8(*(const f32x4*)(qb + 48));
+          const float* kb = Ks + row * EQA_LD + 4 * g;
+          const h8 kh0 = as_h8(*(const f32x4*)(kb)), kh1 = as_h8(*(const f32x4*)(kb + 16));
+          const h8 kl0 = as_h8(*(const f32x4*)(kb + 32)), kl1 = as_h8(*(const f32x4*)(kb + 48));
+          f32x4 S = {0, 0, 0, 0};
+          S = mfma16x32h(kh0, qh0, S);
+          S = mfma16x32h(kh1, qh1, S);
+          S = mfma16x32h(kl0, qh0, S);
+          S = mfma16x32h(kl1, qh1, S);
+          S = mfma16x32h(kh0, ql0, S);
+          S = mfma16x32h(kh1, ql1, S);
+          float m = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            S[i] = 4 * g + i < len ? S[i] * 0.125f : -INFINITY;
+            m = fmaxf(m, S[i]);
+          }
+          m = fmaxf(m, __shfl_xor(m, 16, 64));
+          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          float sum = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            S[i] = 4 * g + i < len ? __expf(S[i] - m) : 0.0f;
+            sum += S[i];
+          }
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          h4 ph, pl;
+          split_f16(S * (1.0f / sum), ph, pl);
+          const h4 z4 = {0, 0, 0, 0};
+          const h8 bh = __builtin_shufflevector(ph, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+          const h8 bl = __builtin_shufflevector(pl, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const _Float16* vb = (const _Float16*)(Vt + (16 * dt + r16) * EQA_LD);
+            h8 ah, al;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int key = min(first + 4 * g + i, 63);
+              ah[i] = vb[key];
+              al[i] = vb[64 + key];
+              ah[4 + i] = (_Float16)0.0f;
+              al[4 + i] = (_Float16)0.0f;
+            }
+            f32x4 o = {0, 0, 0, 0};
+            o = mfma16x32h(ah, bh, o);
+            o = mfma16x32h(al, bh, o);
+            o = mfma16x32h(ah, bl, o);
+            if (r16 < len) *(f32x4*)(a.att + (size_t)(r0 + first + r16) * 256 + 64 * h + 16 * dt + 4 * g) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// qkv[r] = table row of (token[r], pos[r]): the first layer's projection for sentences of 17..64 tokens (amazon), whose
+// attention kernels read plain qkv rows
+__global__ __launch_bounds__(256) void enc_tab_gather_kernel(const float* __restrict__ tab, int tab_len, int vocab,
+                                                             const int32_t* __restrict__ tok, const int32_t* __restrict__ pos,
+                                                             int R, float* __restrict__ qkv) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const int t = min(max(tok[r], 0), vocab - 1), p = min(max(pos[r], 0), tab_len - 1);
+  const float* src = tab + ((size_t)t * tab_len + p) * 768 + lane * 4;
+  float* dst = qkv + (size_t)r * 768 + lane * 4;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) *(f32x4*)(dst + 256 * i) = *(const f32x4*)(src + 256 * i);
+}
+
 // latent[s] = sum over the sentence's rows of sigmoid(LayerNorm_f(x[row]))   (model.py:236-240)
 __global__ __launch_bounds__(256) void enc_latent_kernel(const float* __restrict__ x, const int32_t* __restrict__ off,
                                                          int n_sent, int n_rows, const float* __restrict__ ln_a,
@@ -546,7 +704,15 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     const StEncLayer& y = w->layer[l];
     ST_CHECK_ARG(y.ln0_a && y.ln0_b && y.wqkv && y.bqkv && y.wo && y.bo && y.ln1_a && y.ln1_b && y.w1 && y.b1 && y.w2 && y.b2,
                  "NULL weight pointer in encoder layer %d", l);
-    if (fused) {
+    const bool tab0 = l == 0 && w->l0_table != nullptr && w->l0_table_len >= max_sent_len && w->gemm_format == ST_GEMM_F16X3;
+    if (tab0 && fused) {
+      ST_ENSURE_LDS(enc_tab_attn16_kernel, ETA_LDS);
+      EtaArgs e = {};
+      e.tab = w->l0_table; e.tab_len = w->l0_table_len; e.vocab = w->vocab; e.tokens = tokens; e.tok_pos = tok_pos;
+      e.off = sent_off; e.first_sent = first_sent; e.att = att; e.R = R; e.n_sent = n_sent; e.n_win = n_win;
+      hipLaunchKernelGGL(enc_tab_attn16_kernel, dim3(std::min(n_win, 2 * st_cu_count())), dim3(512), ETA_LDS, st, e);
+      ST_LAUNCH_CHECK();
+    } else if (fused) {
       EqaArgs e = {};
       e.x = x; e.off = sent_off; e.first_sent = first_sent; e.ln_a = y.ln0_a; e.ln_b = y.ln0_b; e.W = y.wqkv; e.bias = y.bqkv;
       e.att = att; e.range_flag = range_flag; e.R = R; e.n_sent = n_sent; e.n_win = n_win;
@@ -558,7 +724,11 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
       g.out = qkv; g.ldo = 768;
       const int qsplits = rp_splits(R, 768, 3, rp_nw(w->gemm_format, 8));
-      if (w->gemm_format == ST_GEMM_F16X3)
+      if (tab0) {
+        hipLaunchKernelGGL(enc_tab_gather_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->l0_table, w->l0_table_len, w->vocab, tokens,
+                           tok_pos, R, qkv);
+        ST_LAUNCH_CHECK();
+      } else if (w->gemm_format == ST_GEMM_F16X3)
         ST_TRY(launch_rp_lin_pipelined<EPI_BIAS>(g, R, qsplits, st));
       else
         ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, qsplits, st)));
@@ -619,6 +789,64 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
                    "the latents are invalid - pack the weights with ST_GEMM_F32");
       return ST_ERANGE;
     }
+  }
+  return ST_OK;
+}
+
+extern "C" size_t st_encode_l0_table_bytes(const StEncoderWeights* w, int positions) {
+  if (!w || positions <= 0 || w->vocab <= 0) return 0;
+  return (size_t)w->vocab * positions * 768 * 4;
+}
+
+__global__ __launch_bounds__(256) void enc_l0_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe, int vocab,
+                                                           int positions, float* __restrict__ x) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long)vocab * positions) return;
+  const int lane = threadIdx.x & 63;
+  const int tok = (int)(r / positions), pos = (int)(r % positions);
+  const f32x4 e = *(const f32x4*)(emb + (size_t)tok * 256 + lane * 4);
+  const f32x4 p = *(const f32x4*)(pe + (size_t)pos * 256 + lane * 4);
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;   // exactly enc_embed_kernel's expression
+}
+
+extern "C" int st_encode_build_l0_table(const StEncoderWeights* w, int positions, float* table, void* scratch,
+                                        size_t scratch_bytes, void* stream) {
+  ST_CHECK_ARG(w != nullptr && table && scratch, "NULL argument");
+  ST_CHECK_ARG(w->d_model == ST_D && w->n_heads == 4 && w->n_layers >= 1, "encoder shape unsupported");
+  ST_CHECK_ARG(w->gemm_format == ST_GEMM_F16X3, "the first-layer table is used by the f16x3 format only");
+  ST_CHECK_ARG(positions >= 1 && positions <= 64 && positions <= w->pe_rows, "positions=%d", positions);
+  const long rows = (long)w->vocab * positions;
+  ST_CHECK_ARG(rows < (1L << 31), "vocab * positions = %ld rows: too large", rows);
+  ST_CHECK_ARG(scratch_bytes >= (size_t)rows * 1024, "scratch too small: need %zu bytes", (size_t)rows * 1024);
+  const StEncLayer& y = w->layer[0];
+  ST_CHECK_ARG(w->emb && w->pe && y.ln0_a && y.ln0_b && y.wqkv && y.bqkv, "NULL weight pointer");
+  hipStream_t st = (hipStream_t)stream;
+  float* x = (float*)scratch;
+  int* flag = nullptr;
+  ST_HIP(hipMalloc(&flag, sizeof(int)));
+  ST_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+  hipLaunchKernelGGL(enc_l0_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, w->emb, w->pe, w->vocab, positions, x);
+  ST_LAUNCH_CHECK();
+  int rc = ST_OK;
+  for (long r0 = 0; r0 < rows && rc == ST_OK; r0 += 1 << 20) {
+    const int n = (int)((rows - r0 < (1L << 20)) ? rows - r0 : (1L << 20));
+    GemmArgs g = {};
+    g.fmt = w->gemm_format; g.range_flag = flag;
+    g.X = x + (size_t)r0 * 256; g.n_host = n; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
+    g.out = table + (size_t)r0 * 768; g.ldo = 768;
+    rc = launch_rp_lin_pipelined<EPI_BIAS>(g, n, 3, st);
+  }
+  int bad = 0;
+  if (rc == ST_OK) {
+    hipError_t e = hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = ST_EHIP;
+  }
+  (void)hipFree(flag);
+  if (rc != ST_OK) return rc;
+  if (bad) {
+    st_set_error("st_encode_build_l0_table: an activation left the f16 range; pack the weights with ST_GEMM_F32");
+    return ST_ERANGE;
   }
   return ST_OK;
 }

@@ -144,6 +144,22 @@ class AEWeights(_Packed):
             y.ln1_a, y.ln1_b = self.dev(sd[p + "sublayer.1.norm.a_2"]), self.dev(sd[p + "sublayer.1.norm.b_2"])
             y.w1, y.b1 = self.packed(sd[p + "feed_forward.w_1.weight"]), self.dev(sd[p + "feed_forward.w_1.bias"])
             y.w2, y.b2 = self.packed(sd[p + "feed_forward.w_2.weight"]), self.dev(sd[p + "feed_forward.w_2.bias"])
+        # the encoder's first layer has the same property (st_kernels.h: StEncoderWeights.l0_table)
+        s.l0_table, s.l0_table_len = None, 0
+        if gemm_format == "f16x3" and l0_table:
+            import ctypes as C
+            T = max_len - 1
+            L = _lib.lib()
+            nbytes = L.st_encode_l0_table_bytes(C.byref(s), T)
+            if 0 < nbytes <= l0_table_max_bytes:
+                tab = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+                scratch = torch.empty(self.vocab * T * 256, dtype=torch.float32, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(L.st_encode_build_l0_table(C.byref(s), T, tab.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                                          torch.cuda.current_stream().cuda_stream), "st_encode_build_l0_table")
+                del scratch
+                self._keep.append(tab)
+                s.l0_table, s.l0_table_len = tab.data_ptr(), T
 
 
 def fold_bn(w, b, bn_w, bn_b, mean, var, eps=1e-5):

@@ -655,3 +655,25 @@ def test_first_layer_table_gives_the_same_decodes(dev, ae_sd_torch, gold_notnll)
     a, ga, _ = ops.greedy_decode(ae, small, want_gap=True, l0_table=True)
     b, gb, _ = ops.greedy_decode(ae, small, want_gap=True, l0_table=False)
     assert torch.equal(a, b) and torch.equal(ga, gb)
+
+
+def test_first_encoder_layer_table_gives_the_same_latents(dev, ae_sd_torch):
+    """StEncoderWeights.l0_table: the first encoder layer's q | k | v per (token, position) from a table instead of a
+    projection per row.  Short sentences (<= 16 tokens: the attention block of the fused kernel on gathered rows) and long
+    ones (17..59 tokens: gathered qkv rows + the general attention kernels) must give bit-identical latents."""
+    from style_transfer_amd import ops
+    from style_transfer_amd.data import pack_sentences
+    from style_transfer_amd.weights import AEWeights
+    with_tab = AEWeights(ae_sd_torch, dev, gemm_format="f16x3")
+    without = AEWeights(ae_sd_torch, dev, gemm_format="f16x3", l0_table=False)
+    assert with_tab.enc.l0_table and not without.enc.l0_table
+    t = lambda v: torch.from_numpy(v).to(dev)
+    rng = np.random.default_rng(4)
+    V = with_tab.vocab
+    short = some_sentences(400, seed=13) + [[5], [7, 9]] + [[int(x) for x in rng.integers(4, V, 16)] for _ in range(5)]
+    long_ = [[int(x) for x in rng.integers(4, V, n)] for n in rng.integers(1, 60, 300)]
+    for sents in (short, long_, short * 40):           # (the last one: ~250 k rows, persistent grids)
+        tok, pos, off, mx = pack_sentences(sents)
+        a = ops.encode_latent(with_tab, t(tok), t(pos), t(off), len(sents), mx)
+        b = ops.encode_latent(without, t(tok), t(pos), t(off), len(sents), mx)
+        assert torch.equal(a, b), (len(sents), mx, float((a - b).abs().max()))
