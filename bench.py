@@ -499,6 +499,108 @@ def main(argv=None):
                                    "log text (st_format_attack_log) -> file (%.0f MB), prefetch and drain threads overlapped "
                                    "with compute" % (len(big), B, nbytes / 1e6))
 
+    def emit():
+        """rank 0: the ONE JSON line, from the timed region's figures and whatever `side` holds by now"""
+        if rank != 0:
+            return
+        if True:
+            achieved = gen_fl.value / (gen_ms.value * 1e-3) / 1e12 if gen_ms.value > 0 else 0.0
+            split = a.gemm_format == "f16x3"
+            peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
+            # HBM-side bytes of the roofline kernel come from rocprofv3 counter passes of THIS command (counters cannot be
+            # read from inside the process): profiles/README.md gives the two commands; tools/traffic_from_pmc.py applies
+            # the guide's gfx950 correction.  Only quoted for the configuration the passes were made on.
+            traffic = traffic_src = alg_bytes = None
+            tfile = os.path.join(ROOT, "profiles", "r03_pmc_bench_half_layer_traffic.json")
+            bfile = os.path.join(ROOT, "profiles", "r03_pmc_phase_mfma_busy.json")
+            busy = None
+            if split and gen_n.value > 0:
+                # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
+                alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
+                default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 49152 and not a.fixed_steps
+                               and a.iters_per_decode == "12,6" and not a.log_decodes)
+                if default_cfg and os.path.exists(tfile):
+                    traffic = json.load(open(tfile))["bytes_per_launch"]
+                    traffic_src = "profiles/r03_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"
+                if default_cfg and os.path.exists(bfile):
+                    busy = json.load(open(bfile))
+                    busy["source"] = "profiles/r03_pmc_phase_mfma_busy.json (SQ counter pass of this command, tools/summarize_pmc.py)"
+            fl = algorithmic_flops(ae, world * B * a.steps, tot[3], tot[4], tot[5], kp, kn, tot[:3])
+            whole = fl["total"] / dt / 1e12
+            # share of the algorithmic flops that run as AE matrix products (3 MFMA flops issued per flop in f16x3)
+            ae_share = (fl["decode"] + fl["encode"]) / fl["total"]
+            out = {
+                "metric": "style-transferred sentences/sec, yelp-shape" if a.shape == "yelp" else "style-transferred sentences/sec, amazon-shape",
+                "value": world * B * a.steps / dt, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32 (AE matrix products: f16 hi+lo split operands, 3 products per term, f32 accumulate)" if split else "f32",
+                "data": "synthetic",
+                "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d; token ids: %s), %d per GPU per step, flags --attack "
+                                       "--not_nll --pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
+                                       "surrogate AE checkpoint + shipped (yelp) Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes %s"
+                                       % (a.shape, {"zipf": "unigram/Zipfian from word_to_id.txt counts", "uniform": "uniform in [4,V)",
+                                                    "real": "the real yelp test set tiled"}[a.tokens], B,
+                                          "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS", "on" if a.log_decodes else "off"),
+                           "distinct_batches": not a.same_batch, "batch_per_gpu": B, "sentences_per_step": world * B,
+                           "parallelism": "sentence-sharded x%d" % world,
+                           "mean_edit_iterations_per_sentence": n_iter_mean,
+                           "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
+                           "iters_per_decode": cfg.iters_per_decode, "sync_every": cfg.sync_every, "gemm_format": a.gemm_format,
+                           "edit_iteration_units_per_s": tot[3] / dt,
+                           "side_runs_same_workload_one_gpu": (side or None) if world == 1 else None,
+                           "end_to_end_with_final_gather": (side or None) if world > 1 else None},
+                # the whole timed region against the MFMA roofline (SURVEY 8d): executed algorithmic flops / wall time
+                "whole_step": {"executed_token_steps": tot[0], "keys_attended": tot[1], "decode_jobs_executed": tot[2],
+                               "decode_jobs_needed": world * B * a.steps + tot[3],
+                               "encoder_token_rows": tot[4],
+                               "algorithmic_flops": fl, "algorithmic_tflops": whole, "peak": peak, "frac": whole / peak,
+                               "mfma_issue_frac": whole * ((3 * ae_share + (1 - ae_share)) if split else 1) / peak,
+                               # counters cannot be read from inside the process: quoted from the committed counter pass of this command
+                               "mfma_busy": busy,
+                               "note": "F_tok = 2[N(4d^2 + 2 d d_ff) + d V] + 2048 t per executed token-step (KV cache, cross-attention "
+                                       "folded, no log-softmax) + encoder + scorer; token-steps counted on the device from the live "
+                                       "counts; wall time includes every launch gap, host sync and the non-GEMM kernels"},
+                # achieved = ALGORITHMIC flops of the timed kernel / its HIP-event time.  f16x3 issues 3 MFMA flops per
+                # algorithmic flop, so frac <= 1/3 there by construction; mfma_issue_frac counts the issued ones.
+                "roofline": {"bound": "mfma",
+                             "kernel": ("rp_layer_tail16_kernel (O-projection + residual + LayerNorm + FFN1 + FFN2 on 64-row panels, persistent "
+                                        "over panels, v_mfma_f32_16x16x32_f16; 2*rows*256*(256+2*d_ff) flop per launch; largest share of GPU "
+                                        "time in this format)") if split
+                                       else "rp_gemm_kernel<EPI_ARGMAX,4,false> (generator GEMM + fused argmax; 2*rows*256*V flop per launch)",
+                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                             "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
+                             "traffic_source": traffic_src,
+                             "algorithmic_bytes_per_launch": alg_bytes,
+                             "mfma_flops_per_algorithmic_flop": 3 if split else 1,
+                             "mfma_issue_frac": achieved * (3 if split else 1) / peak,
+                             "achieved_over_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
+                             # a bare loop of this MFMA shape on random operands sustains 1.82 PFLOP/s on this chip (power-managed
+                             # clock; tools/kbench.cpp `p`, profiles/r02_mfma_sustained_rate.txt) - the guide's 2516.6 assumes 2.4 GHz
+                             "mfma_issue_frac_of_sustained_rate": (achieved * 3 / SUSTAINED_F16_16x16x32_TFLOPS) if split else None,
+                             "launches": int(gen_n.value), "avg_launch_us": gen_ms.value * 1e3 / max(1, gen_n.value),
+                             "kernel_time_share": gen_ms.value * 1e-3 / dt},
+            }
+            if world == 1 and not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.shape)
+            print(json.dumps(out), flush=True)
+
+    # The N > 1 side run below is the only part of this file that moves data through RCCL (send / recv of the lean records).
+    # Its figures are a bonus: if it does not finish in time (a collective that waits on a peer forever), rank 0 still prints
+    # the line with the timed region's numbers and every rank leaves with 0 instead of taking the whole run down.
+    import threading
+    wd = None
+    if world > 1 and not a.no_side_runs and not a.fixed_steps:
+        def give_up():
+            side.clear()
+            side["error"] = "end-to-end side run did not finish within %s s: skipped" % os.environ.get("ST_BENCH_E2E_TIMEOUT_S", "300")
+            try:
+                emit()
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+        wd = threading.Timer(float(os.environ.get("ST_BENCH_E2E_TIMEOUT_S", "300")), give_up)
+        wd.daemon = True
+        wd.start()
     # ---- N > 1: what BASELINE config 4 names ("... with final all-gather"): every rank streams its shard through the
     # product pipeline (host token arrays -> pack -> H2D -> attack -> lean records), the records of all ranks go to rank 0
     # (pipeline.gather_to_rank0: RCCL send / recv over xGMI), rank 0 formats the log in global order and writes the file.
@@ -561,86 +663,9 @@ def main(argv=None):
                                    "exact-size send / recv), rank 0 formats %d sentences in global order and writes the file "
                                    "(%.0f MB, log_write_ms); times are the max over ranks" % (len(big), B, world * len(big), nbytes / 1e6))
 
-    if rank == 0:
-        achieved = gen_fl.value / (gen_ms.value * 1e-3) / 1e12 if gen_ms.value > 0 else 0.0
-        split = a.gemm_format == "f16x3"
-        peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
-        # HBM-side bytes of the roofline kernel come from rocprofv3 counter passes of THIS command (counters cannot be
-        # read from inside the process): profiles/README.md gives the two commands; tools/traffic_from_pmc.py applies
-        # the guide's gfx950 correction.  Only quoted for the configuration the passes were made on.
-        traffic = traffic_src = alg_bytes = None
-        tfile = os.path.join(ROOT, "profiles", "r03_pmc_bench_half_layer_traffic.json")
-        bfile = os.path.join(ROOT, "profiles", "r03_pmc_phase_mfma_busy.json")
-        busy = None
-        if split and gen_n.value > 0:
-            # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
-            alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
-            default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 49152 and not a.fixed_steps
-                           and a.iters_per_decode == "12,6" and not a.log_decodes)
-            if default_cfg and os.path.exists(tfile):
-                traffic = json.load(open(tfile))["bytes_per_launch"]
-                traffic_src = "profiles/r03_pmc_bench_half_layer_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes of this command)"
-            if default_cfg and os.path.exists(bfile):
-                busy = json.load(open(bfile))
-                busy["source"] = "profiles/r03_pmc_phase_mfma_busy.json (SQ counter pass of this command, tools/summarize_pmc.py)"
-        fl = algorithmic_flops(ae, world * B * a.steps, tot[3], tot[4], tot[5], kp, kn, tot[:3])
-        whole = fl["total"] / dt / 1e12
-        # share of the algorithmic flops that run as AE matrix products (3 MFMA flops issued per flop in f16x3)
-        ae_share = (fl["decode"] + fl["encode"]) / fl["total"]
-        out = {
-            "metric": "style-transferred sentences/sec, yelp-shape" if a.shape == "yelp" else "style-transferred sentences/sec, amazon-shape",
-            "value": world * B * a.steps / dt, "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (AE matrix products: f16 hi+lo split operands, 3 products per term, f32 accumulate)" if split else "f32",
-            "data": "synthetic",
-            "config": {"workload": "%s-shaped synthetic sentences (SURVEY.md §8d; token ids: %s), %d per GPU per step, flags --attack "
-                                   "--not_nll --pos_victim_lr=0.2 --neg_victim_lr=0.2, max_iter 18, max_change 7, 10 like + 10 unlike, "
-                                   "surrogate AE checkpoint + shipped (yelp) Siamese/Predictor weights, %s, Rec/Sim/Ref log decodes %s"
-                                   % (a.shape, {"zipf": "unigram/Zipfian from word_to_id.txt counts", "uniform": "uniform in [4,V)",
-                                                "real": "the real yelp test set tiled"}[a.tokens], B,
-                                      "fixed 59 decode steps" if a.fixed_steps else "early exit at EOS", "on" if a.log_decodes else "off"),
-                       "distinct_batches": not a.same_batch, "batch_per_gpu": B, "sentences_per_step": world * B,
-                       "parallelism": "sentence-sharded x%d" % world,
-                       "mean_edit_iterations_per_sentence": n_iter_mean,
-                       "setup_ms_per_step": setup_s / a.steps * 1e3, "edit_loop_ms_per_step": loop_s / a.steps * 1e3,
-                       "iters_per_decode": cfg.iters_per_decode, "sync_every": cfg.sync_every, "gemm_format": a.gemm_format,
-                       "edit_iteration_units_per_s": tot[3] / dt,
-                       "side_runs_same_workload_one_gpu": (side or None) if world == 1 else None,
-                       "end_to_end_with_final_gather": (side or None) if world > 1 else None},
-            # the whole timed region against the MFMA roofline: executed algorithmic flops / wall time
-            "whole_step": {"executed_token_steps": tot[0], "keys_attended": tot[1], "decode_jobs_executed": tot[2],
-                           "decode_jobs_needed": world * B * a.steps + tot[3],
-                           "encoder_token_rows": tot[4],
-                           "algorithmic_flops": fl, "algorithmic_tflops": whole, "peak": peak, "frac": whole / peak,
-                           "mfma_issue_frac": whole * ((3 * ae_share + (1 - ae_share)) if split else 1) / peak,
-                           # counters cannot be read from inside the process: quoted from the committed counter pass of this command
-                           "mfma_busy": busy,
-                           "note": "F_tok = 2[N(4d^2 + 2 d d_ff) + d V] + 2048 t per executed token-step (KV cache, cross-attention "
-                                   "folded, no log-softmax) + encoder + scorer; token-steps counted on the device from the live "
-                                   "counts; wall time includes every launch gap, host sync and the non-GEMM kernels"},
-            # achieved = ALGORITHMIC flops of the timed kernel / its HIP-event time.  f16x3 issues 3 MFMA flops per
-            # algorithmic flop, so frac <= 1/3 there by construction; mfma_issue_frac counts the issued ones.
-            "roofline": {"bound": "mfma",
-                         "kernel": ("rp_layer_tail16_kernel (O-projection + residual + LayerNorm + FFN1 + FFN2 on 64-row panels, persistent "
-                                    "over panels, v_mfma_f32_16x16x32_f16; 2*rows*256*(256+2*d_ff) flop per launch; largest share of GPU "
-                                    "time in this format)") if split
-                                   else "rp_gemm_kernel<EPI_ARGMAX,4,false> (generator GEMM + fused argmax; 2*rows*256*V flop per launch)",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "mfma_flops_per_algorithmic_flop": 3 if split else 1,
-                         "mfma_issue_frac": achieved * (3 if split else 1) / peak,
-                         "achieved_over_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
-                         # a bare loop of this MFMA shape on random operands sustains 1.82 PFLOP/s on this chip (power-managed
-                         # clock; tools/kbench.cpp `p`, profiles/r02_mfma_sustained_rate.txt) - the guide's 2516.6 assumes 2.4 GHz
-                         "mfma_issue_frac_of_sustained_rate": (achieved * 3 / SUSTAINED_F16_16x16x32_TFLOPS) if split else None,
-                         "launches": int(gen_n.value), "avg_launch_us": gen_ms.value * 1e3 / max(1, gen_n.value),
-                         "kernel_time_share": gen_ms.value * 1e-3 / dt},
-        }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, a.shape)
-        print(json.dumps(out), flush=True)
+    if wd is not None:
+        wd.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -217,15 +217,27 @@ class AttackRunner:
         """Host -> device: pack the 1 + K+ + K- sentences of every origin (order: all origins, all
         like groups, all unlike groups) into device token arrays, in chunks of ENC_CHUNK sentences."""
         sents = batch.all_sentences()            # one flat token array + offsets (data.Ragged): no per-sentence Python
-        dev, chunks = self.device, []
+        dev, chunks, host = self.device, [], []
+
+        def h2d(x):
+            """numpy -> device through a PINNED staging buffer that the returned dict keeps alive: the copy is asynchronous
+            on the current stream and must not depend on how the runtime stages pageable memory"""
+            src = torch.from_numpy(np.ascontiguousarray(x))
+            pin = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            pin.copy_(src)
+            host.append(pin)
+            return pin.to(dev, non_blocking=True)
         for c0 in range(0, len(sents), self.ENC_CHUNK):
             c1 = min(len(sents), c0 + self.ENC_CHUNK)
             tokens, tok_pos, sent_off, max_len = pack_sentences(sents.span(c0, c1))
-            chunks.append((torch.from_numpy(tokens).to(dev, non_blocking=True), torch.from_numpy(tok_pos).to(dev, non_blocking=True),
-                           torch.from_numpy(sent_off).to(dev, non_blocking=True), c1 - c0, max_len))
-        return dict(chunks=chunks, B=len(batch), kp=batch.n_pos, kn=batch.n_neg)
+            chunks.append((h2d(tokens), h2d(tok_pos), h2d(sent_off), c1 - c0, max_len))
+        return dict(chunks=chunks, B=len(batch), kp=batch.n_pos, kn=batch.n_neg, _host=host)
 
     def encode_prepared(self, prep):
+        cur = torch.cuda.current_stream(self.device)
+        for (t, p, o, _, _) in prep["chunks"]:      # a prefetch thread may have allocated them on its side stream
+            for x in (t, p, o):
+                x.record_stream(cur)
         outs = [ops.encode_latent(self.ae, t, p, o, n, mx, ws=self.ws) for (t, p, o, n, mx) in prep["chunks"]]
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 

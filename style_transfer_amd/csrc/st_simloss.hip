@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __res
 // Operand format of the similarity GEMMs (ST_GEMM_*).  F16X3 (default): unit rows lie in [-1, 1] and dS in [-1, 1], the
 // ideal domain of the hi + lo split (f32-grade: ~2^-22 per term), and every product of the block runs on the f16 MFMA.
 static int g_sl_format = ST_GEMM_F16X3;
+static int g_sl_fused = getenv("ST_AB_ENABLE") && getenv("ST_AB_SIMLOSS_CHUNKED") ? 0 : 1;  // A/B: the round-2 chunked backward
 extern "C" int st_simloss_format(int gemm_format) {
   const int prev = g_sl_format;
   if (gemm_format == ST_GEMM_F32 || gemm_format == ST_GEMM_F16X3) g_sl_format = gemm_format;
@@ -96,6 +97,223 @@ static int sl_pack(const float* W, int N, int K, float* out, hipStream_t st) {
     hipLaunchKernelGGL(pack_weight_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, out);
   }
   ST_LAUNCH_CHECK();
+  return ST_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward block (f16x3 format, round 3): for a 64-row panel of one side's unit rows and a range of 256-column
+// chunks of the other side,
+//     S  = panel . other^T            (split-f16 operands, three products)        [64, 256] per chunk
+//     dS = exp(S / tau - lse) - [target]                                          in registers -> LDS as split f16
+//     acc += dS . other'                                                          [64, 256], other' = the other side's rows
+// i.e. the structure of the decoder's half-layer kernel (rp_layer_tail16_kernel, st_rowpanel.h) with the ReLU replaced by
+// the softmax gradient and the hidden width by the other side's row count: dS never goes to HBM (the chunked form below
+// wrote and re-read 2 x 64 MB per 2048 rows).  Two launches per view: TR = false, panel = queries (ou), lse per ROW,
+// result d_ou;  TR = true, panel = keys (ku), lse per COLUMN, other' = s_i ou_i, result d_ku.  v_mfma_f32_16x16x32_f16,
+// W as the A operand; lane (r16 = l & 15, g = l >> 4) holds columns 4g..4g+3 (+16 ft) of panel row r16 (+16 rt).
+// Column splits (blockIdx.y) write partial sums to a slab that slab_reduce_kernel adds in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct SlbArgs {
+  const float* X;      // [n, 256] unit rows of the panel side
+  int n;               // rows (multiple of 64)
+  const float* w1;     // packed f16x3 image of the other side  [Ncols][256]
+  const float* w2;     // packed f16x3 image of other'^T        [256][Ncols]
+  int Ncols;           // multiple of 256
+  int chunks_per_split;
+  const float* lse;    // TR ? [Ncols] : [n]
+  float scale;         // 1 / tau
+  int tgt_off;         // target column of panel row R: R + tgt_off
+  float* out;          // [gridDim.y][n][256] partial sums
+};
+#define SLB_LDS (2 * 64 * ST_LDA * 4)
+
+template <bool TR>
+__global__ __launch_bounds__(512, 2) void sl_bwd16_kernel(SlbArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* P1 = smem;
+  float* P2 = smem + 64 * ST_LDA;
+  const int m0 = blockIdx.x * 64;
+  const int nchunk = a.Ncols >> 8;
+  const int c_lo = blockIdx.y * a.chunks_per_split;
+  const int c_hi = min(nchunk, c_lo + a.chunks_per_split);
+  if (m0 >= a.n || c_lo >= c_hi) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int fcol = wave * 32 + 4 * g;
+  const int wlane = (g >> 1) * 128 + 32 * (g & 1) + r16;
+  auto W1p = [&](int c) { return (const f32x4*)a.w1 + (size_t)(c * 8 + wave) * 16 * 128 + wlane; };
+  auto W2p = [&](int c) { return (const f32x4*)a.w2 + ((size_t)wave * (a.Ncols >> 4) + c * 16) * 128 + wlane; };
+  f32x4 rw[2][4];
+  auto wfetch = [&](const f32x4* Wl, int d, f32x4 (&dst)[4]) {
+    dst[0] = Wl[d * 256];
+    dst[1] = Wl[d * 256 + 64];
+    dst[2] = Wl[d * 256 + 16];
+    dst[3] = Wl[d * 256 + 80];
+  };
+  wfetch(W1p(c_lo), 0, rw[0]);
+  wfetch(W1p(c_lo), 1, rw[1]);
+  int bad = 0;
+  {
+    f32x4 xr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + i * 512;
+      xr[i] = *(const f32x4*)(a.X + (size_t)(m0 + (f >> 6)) * 256 + (f & 63) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = tid + i * 512;
+      panel_store4_nb16(P1 + (f >> 6) * ST_LDA, f & 63, xr[i], bad);
+    }
+  }
+  float lrow[4];
+  int tgt[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int R = m0 + 16 * rt + r16;
+    lrow[rt] = TR ? 0.0f : a.lse[R];
+    tgt[rt] = R + a.tgt_off;
+  }
+  f32x4 lcc[2], lcn[2];  // TR: lse of this lane's 8 columns, chunk being converted / next chunk
+  auto lc_fetch = [&](int c, f32x4 (&dst)[2]) {
+    if (TR) {
+      dst[0] = *(const f32x4*)(a.lse + (c * 8 + wave) * 32 + 4 * g);
+      dst[1] = *(const f32x4*)(a.lse + (c * 8 + wave) * 32 + 16 + 4 * g);
+    }
+  };
+  lc_fetch(c_lo, lcc);
+  const float* A1 = P1 + r16 * ST_LDA + rp16_frag_pos(0, g);
+  const float* A2 = P2 + r16 * ST_LDA + rp16_frag_pos(0, g);
+  _Float16* H2 = (_Float16*)P2;
+  int cconv = c_lo;  // the chunk whose S tile is being turned into dS
+  auto epi_unit = [&](const f32x4& acc, int ft, int rt) {
+    const int col0 = (cconv * 8 + wave) * 32 + 16 * ft + 4 * g;
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x = fminf(fmaf(acc[q], a.scale, -(TR ? lcc[ft][q] : lrow[rt])), 10.0f);  // <= 0 up to rounding for a matching lse
+      v[q] = __expf(x) - (col0 + q == tgt[rt] ? 1.0f : 0.0f);
+    }
+    h4 hi, lo;
+    split_f16(v, hi, lo);
+    _Float16* dst = H2 + (size_t)(16 * rt + r16) * (2 * ST_LDA) + 2 * rp16_quad_pos((fcol + 16 * ft) >> 2);
+    *(h4*)dst = hi;
+    *(h4*)(dst + 256) = lo;
+  };
+  auto pass = [&](const float* Pb, const f32x4* Wc, const f32x4* Wn, f32x4 (&acc)[2][4], const bool epi, const f32x4 (&o)[2][4]) {
+    f32x4 pn[4];
+    pn[0] = *(const f32x4*)(Pb);
+    pn[1] = *(const f32x4*)(Pb + 128);
+    pn[2] = *(const f32x4*)(Pb + 16 * ST_LDA);
+    pn[3] = *(const f32x4*)(Pb + 16 * ST_LDA + 128);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int slot = d & 1;
+      const h8 wh0 = as_h8(rw[slot][0]), wl0 = as_h8(rw[slot][1]), wh1 = as_h8(rw[slot][2]), wl1 = as_h8(rw[slot][3]);
+      if (d + 2 < 8)
+        wfetch(Wc, d + 2, rw[slot]);
+      else
+        wfetch(Wn, d + 2 - 8, rw[slot]);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+        if (!(d == 7 && hf == 1)) {
+          const int nd = hf ? d + 1 : d, nrt = hf ? 0 : 2;
+          const float* q = Pb + nrt * 16 * ST_LDA + 8 * nd;
+          pn[0] = *(const f32x4*)(q);
+          pn[1] = *(const f32x4*)(q + 128);
+          pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+          pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+        }
+        const int rt = 2 * hf;
+        acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
+        acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
+        acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
+        acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
+        acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
+        if (epi && hf == 1) epi_unit(o[d & 1][d >> 1], d & 1, d >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto zero = [&](f32x4 (&h)[2][4]) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) h[ft][rt] = f32x4{0, 0, 0, 0};
+  };
+  f32x4 ax[2][4], ah[2][4];
+  zero(ax);
+  zero(ah);
+  __syncthreads();  // the panel is in P1
+  pass(A1, W1p(c_lo), c_lo + 1 < c_hi ? W1p(c_lo + 1) : W2p(c_lo), ah, false, ah);
+  for (int c = c_lo; c + 1 < c_hi; ++c) {
+    f32x4 an[2][4];
+    zero(an);
+    lc_fetch(c + 1, lcn);
+    if (c > c_lo) __syncthreads();  // every wave is done reading the previous dS chunk
+    cconv = c;
+    pass(A1, W1p(c + 1), W2p(c), an, true, ah);  // S of chunk c + 1; chunk c -> dS -> P2 in the MFMAs' shadow
+    __syncthreads();                             // dS chunk complete
+    pass(A2, W2p(c), c + 2 < c_hi ? W1p(c + 2) : W2p(c + 1), ax, false, ax);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) ah[ft][rt] = an[ft][rt];
+    if (TR) {
+      lcc[0] = lcn[0];
+      lcc[1] = lcn[1];
+    }
+  }
+  {
+    const int c = c_hi - 1;
+    if (c > c_lo) __syncthreads();
+    cconv = c;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) epi_unit(ah[ft][rt], ft, rt);
+    __syncthreads();
+    pass(A2, W2p(c), W2p(c), ax, false, ax);  // (the ring's last prefetch re-reads this chunk's first steps and drops them)
+  }
+  float* o = a.out + ((size_t)blockIdx.y * a.n + m0) * 256;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    *(f32x4*)(o + (size_t)(16 * rt + r16) * 256 + fcol) = ax[0][rt];
+    *(f32x4*)(o + (size_t)(16 * rt + r16) * 256 + fcol + 16) = ax[1][rt];
+  }
+  (void)bad;  // unit rows lie in [-1, 1]
+}
+
+// rows: panel side (multiple of 64), cols: other side (multiple of 256); dst [rows, 256]
+template <bool TR>
+static int sl_bwd_fused(const float* Xrows, int rows, const float* W1packed, const float* W2packed, int cols, const float* lse,
+                        float scale, int tgt_off, float* slab, size_t slab_rows, float* dst, hipStream_t st) {
+  ST_ENSURE_LDS((sl_bwd16_kernel<TR>), SLB_LDS);
+  const int panels = rows / 64, nchunk = cols / 256;
+  const int cus = st_cu_count();
+  // column splits: about one workgroup per CU (133 KiB of LDS: one resident workgroup), whole chunks, slab permitting
+  int splits = std::max(1, std::min(nchunk, (cus + panels / 2) / panels));
+  while (splits > 1 && (size_t)splits * rows > slab_rows) --splits;
+  const int cps = (nchunk + splits - 1) / splits;
+  splits = (nchunk + cps - 1) / cps;
+  SlbArgs a = {Xrows, rows, W1packed, W2packed, cols, cps, lse, scale, tgt_off, splits > 1 ? slab : dst};
+  hipLaunchKernelGGL(sl_bwd16_kernel<TR>, dim3(panels, splits), dim3(512), SLB_LDS, st, a);
+  ST_LAUNCH_CHECK();
+  if (splits > 1) {
+    const size_t n4 = (size_t)rows * 64;
+    hipLaunchKernelGGL(slab_reduce_kernel<0>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, splits, n4, dst, n4);
+    ST_LAUNCH_CHECK();
+  }
   return ST_OK;
 }
 
@@ -232,8 +450,14 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
       }
       return ST_OK;
     };
-    ST_TRY(chunked(w.ou, Bq, w.kup, Bk, 0, w.kutp, w.dou, 0));
-    ST_TRY(chunked(w.ku, Bk, w.oup, Bq, 1, w.oustp, w.dku, 0));
+    if (g_sl_fused) {
+      const size_t slab_rows = (size_t)SL_KSPLIT * SL_CHUNK;
+      ST_TRY(sl_bwd_fused<false>(w.ou, Bq, w.kup, w.kutp, Bk, lse, scale, row_offset, w.slab, slab_rows, w.dou, st));
+      ST_TRY(sl_bwd_fused<true>(w.ku, Bk, w.oup, w.oustp, Bq, lse, scale, -row_offset, w.slab, slab_rows, w.dku, st));
+    } else {
+      ST_TRY(chunked(w.ou, Bq, w.kup, Bk, 0, w.kutp, w.dou, 0));
+      ST_TRY(chunked(w.ku, Bk, w.oup, Bq, 1, w.oustp, w.dku, 0));
+    }
     hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, w.dou, w.ou, w.on, Bq, d_ori, 0, (const float*)w.rs);
     hipLaunchKernelGGL(unit_rows_bwd_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, w.dku, w.ku, w.kn, Bk, d_like, 1, (const float*)nullptr);
     ST_LAUNCH_CHECK();
