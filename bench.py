@@ -72,9 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=49152,
-                    help="sentences per GPU per step (KV cache: 241 KB per decode job, 13 jobs per sentence in the first round: 154 GB of "
-                         "the 288 GB at the default; 32768 -> 113.6 k, 49152 -> 121.2 k, 65536 -> 123.0 k sentences/s)")
+    ap.add_argument("--batch", type=int, default=98304,
+                    help="sentences per GPU per step (K/V cache: 121 KB per decode job with the first-layer table, 13 jobs per sentence in "
+                         "the first round: 155 GB of the 288 GB at the default; same box: 49152 -> 165.5 k, 65536 -> 170.3 k, 81920 -> "
+                         "172.0 k, 98304 -> 174.9 k, 114688 -> 165.1 k sentences/s)")
     ap.add_argument("--shape", default="yelp", choices=["yelp", "amazon"])
     ap.add_argument("--tokens", default="zipf", choices=["zipf", "uniform", "real"],
                     help="synthetic token ids: unigram (Zipfian) from word_to_id.txt counts, uniform in [4,V), or the "
@@ -437,7 +438,10 @@ def main(argv=None):
         sc32 = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_params.safetensors")),
                                W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev, gemm_format="f32")
         r32 = AttackRunner(ae32, sc32, cfg, dev)
-        side["exact_f32_format_sentences_per_s"] = timed(r32, preps[:2])
+        # (no first-layer table in this format: 241 KB of K/V cache per job, so at most 32768 sentences per batch)
+        B32 = min(B, 32768)
+        side["exact_f32_format_sentences_per_s"] = timed(r32, [runner.prepare(s.span(0, B32)) for s in sets[:2]])
+        side["exact_f32_format_batch"] = B32
         r32.ws.buf = None
         del r32, ae32
         fresh()
@@ -517,7 +521,7 @@ def main(argv=None):
             if split and gen_n.value > 0:
                 # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
                 alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
-                default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 49152 and not a.fixed_steps
+                default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 98304 and not a.fixed_steps
                                and a.iters_per_decode == "12,6" and not a.log_decodes)
                 if default_cfg and os.path.exists(tfile):
                     traffic = json.load(open(tfile))["bytes_per_launch"]

@@ -192,6 +192,9 @@ int st_decode_build_l0_table(const StDecoderWeights* w, int positions, float* ta
 
 /* bytes of device workspace st_decode_greedy needs for B sentences */
 size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len);
+/* the same for the `options` the call will pass to st_decode_greedy (ST_DEC_*): when the first layer reads l0_table it keeps no
+ * K / V cache, and the workspace is about half the size st_decode_workspace_bytes (which covers every option) returns */
+size_t st_decode_workspace_bytes_opt(const StDecoderWeights* w, int B, int max_len, int options);
 
 /* options for st_decode_greedy */
 #define ST_DEC_EARLY_EXIT 1   /* stop a sentence at its first EOS/PAD token (output-equivalent:

@@ -94,6 +94,7 @@ EXPORTS = {
     "st_decode_l0_table_bytes": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int]),
     "st_decode_build_l0_table": (C.c_int, [C.POINTER(StDecoderWeights), C.c_int, fp, fp, C.c_size_t, fp]),
     "st_decode_workspace_bytes": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int, C.c_int]),
+    "st_decode_workspace_bytes_opt": (C.c_size_t, [C.POINTER(StDecoderWeights), C.c_int, C.c_int, C.c_int]),
     "st_decode_greedy": (C.c_int, [C.POINTER(StDecoderWeights), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, fp, fp, fp, C.c_size_t, C.POINTER(C.c_int), fp]),
     "st_gemm_argmax": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp]),

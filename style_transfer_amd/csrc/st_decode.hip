@@ -687,7 +687,8 @@ struct DecodeWs {
 #define ST_SYNC_RELAX_ROWS 1024  /* below this many live rows the host reads the live count every 4th step only */
 #define ST_GEN_SPLITS_SMALL 96  /* ... when few rows are live: the late steps are latency-bound on streaming W */
 
-static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base) {
+// kv_layers: decoder layers that keep a K / V cache (all of them, or all but the first when it reads the (token, position) table)
+static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base, int kv_layers) {
   DecodeWs ws;
   const int T = max_len - 1, L = w->n_layers;
   size_t off = 0;
@@ -696,7 +697,7 @@ static DecodeWs carve(const StDecoderWeights* w, int B, int max_len, char* base)
     off += align_up(bytes, 256);
     return p;
   };
-  ws.kv = (float*)take((size_t)B * L * 2 * T * 256 * 4);
+  ws.kv = (float*)take((size_t)B * (kv_layers > 0 ? kv_layers : 1) * 2 * T * 256 * 4);
   ws.x = (float*)take((size_t)B * 256 * 4);
   ws.q = (float*)take((size_t)B * 256 * 4);
   ws.att = (float*)take((size_t)B * 256 * 4);
@@ -733,9 +734,15 @@ static int check_weights(const StDecoderWeights* w, int max_len) {
   return ST_OK;
 }
 
-extern "C" size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len) {
+static bool dec_uses_l0_table(const StDecoderWeights* w, int max_len, int options) {
+  return w->l0_table != nullptr && w->l0_table_len >= max_len - 1 && w->gemm_format == ST_GEMM_F16X3 && !(options & ST_DEC_NO_L0_TABLE);
+}
+extern "C" size_t st_decode_workspace_bytes_opt(const StDecoderWeights* w, int B, int max_len, int options) {
   if (!w || B <= 0 || max_len < 2) return 0;
-  return carve(w, B, max_len, nullptr).total;
+  return carve(w, B, max_len, nullptr, w->n_layers - (dec_uses_l0_table(w, max_len, options) ? 1 : 0)).total;
+}
+extern "C" size_t st_decode_workspace_bytes(const StDecoderWeights* w, int B, int max_len) {
+  return st_decode_workspace_bytes_opt(w, B, max_len, ST_DEC_NO_L0_TABLE);   // enough for every option
 }
 
 extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, int B, int max_len, int bos, int eos,
@@ -750,13 +757,15 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   ST_CHECK_ARG(sync_every >= 1, "sync_every=%d must be >= 1", sync_every);
   hipStream_t st = (hipStream_t)stream;
   const int T = max_len - 1, L = w->n_layers;
-  DecodeWs ws = carve(w, B, max_len, (char*)workspace);
+  const bool use_tab = dec_uses_l0_table(w, max_len, options);
+  const int kv_first = use_tab ? 1 : 0, kv_layers = L - kv_first;   // the first layer keeps no K / V cache when it reads the table
+  DecodeWs ws = carve(w, B, max_len, (char*)workspace, kv_layers);
   if (ws.total > workspace_bytes) {
     st_set_error("workspace too small: need %zu bytes, have %zu", ws.total, workspace_bytes);
     return ST_ENOMEM;
   }
   const int early = (options & ST_DEC_EARLY_EXIT) ? 1 : 0;
-  const long kv_stride = (long)L * 2 * T * 256;
+  const long kv_stride = (long)(kv_layers > 0 ? kv_layers : 1) * 2 * T * 256;
   unsigned long long* work = nullptr;
   ST_TRY(st_work_counters_ptr(&work));
 
@@ -791,7 +800,6 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   // attn_step16_kernel keeps 12 independent rows per CU in flight all the time.
   const bool fuse_qkv_attn = w->gemm_format == ST_GEMM_F16X3 && rp_dec_fused && kv_stride % 4 == 0 && ((size_t)ws.kv & 15) == 0;
   const int fuse_min_rows = 1;
-  const bool use_tab = w->l0_table != nullptr && w->l0_table_len >= T && w->gemm_format == ST_GEMM_F16X3 && !(options & ST_DEC_NO_L0_TABLE);
   int n_bound = B;
   int cur = 0;
   int steps = 0;
@@ -806,8 +814,9 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     ST_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
       const StDecLayer& y = w->layer[l];
-      float* kb = ws.kv + (size_t)(l * 2 + 0) * T * 256;
-      float* vb = ws.kv + (size_t)(l * 2 + 1) * T * 256;
+      const int lk = l - kv_first;   // this layer's place in the K / V cache (-1: the table layer keeps none)
+      float* kb = lk >= 0 ? ws.kv + (size_t)(lk * 2 + 0) * T * 256 : nullptr;
+      float* vb = lk >= 0 ? ws.kv + (size_t)(lk * 2 + 1) * T * 256 : nullptr;
       if (l == 0 && use_tab) {
         // first layer: q | k | v of (token, position) from the table; no projection, no K / V cache rows
         if (pos < 16)

@@ -57,13 +57,13 @@ def greedy_decode(ae, latent, max_len=60, start_id=2, eos=3, pad=0, early_exit=T
     gap = torch.empty(B, T, dtype=torch.float32, device=latent.device) if want_gap else None
     if B == 0:
         return ids, gap, 0
-    need = lib().st_decode_workspace_bytes(C.byref(ae.dec), B, max_len)
+    options = ((_lib.ST_DEC_EARLY_EXIT if early_exit else 0) | (0 if screen else _lib.ST_DEC_NO_SCREEN) |
+               (0 if l0_table else _lib.ST_DEC_NO_L0_TABLE))
+    need = lib().st_decode_workspace_bytes_opt(C.byref(ae.dec), B, max_len, options)
     ws = ws or DecodeWorkspace(latent.device)
     buf = ws.get(need)
     steps = C.c_int(0)
-    check(lib().st_decode_greedy(C.byref(ae.dec), latent.data_ptr(), B, max_len, start_id, eos, pad,
-                                 (_lib.ST_DEC_EARLY_EXIT if early_exit else 0) | (0 if screen else _lib.ST_DEC_NO_SCREEN) |
-                                 (0 if l0_table else _lib.ST_DEC_NO_L0_TABLE),
+    check(lib().st_decode_greedy(C.byref(ae.dec), latent.data_ptr(), B, max_len, start_id, eos, pad, options,
                                  sync_every, ids.data_ptr(), _p(gap),
                                  buf.data_ptr(), buf.numel(), C.byref(steps), _stream()), "st_decode_greedy")
     return ids, gap, steps.value
