@@ -16,6 +16,9 @@
 #define SC_NW 8          // waves per workgroup; two workgroups per CU (79 KiB of LDS each) = 4 waves per SIMD
 #define SC_RPW (SC_ROWS / SC_NW)  // rows per wave in the row-wise phases
 #define SC_BUF (SC_ROWS * SC_LD)
+#ifndef SC_ZCH
+#define SC_ZCH 10     // like / unlike unit vectors requested together in the score phase
+#endif
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
 enum { BWD_NONE = 0, BWD_RELU = 1, BWD_LRELU = 2 };
@@ -241,11 +244,27 @@ __device__ __forceinline__ f32x4 score_row(const ScorerArgs& a, int m0, int n, i
                                            int np, int nn, int nt, float inv_tau) {
   const int lane = threadIdx.x & 63;
   const float pn = fmaxf(sqrtf(wave_sum(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w)), 1e-8f);
-  for (int j = 0; j < nt; ++j) {
+  // The unit vectors come from HBM (20 KB per sentence): SC_ZCH rows are requested together, so a row costs nt / SC_ZCH
+  // memory round trips instead of nt (one wave walks its rows alone: with one load in flight the score phase was a fifth
+  // of the kernel's time).  Same operations in the same order as the one-at-a-time loop.
+  auto zrow = [&](int j) {
+#ifdef SC_ABL_NOZ
+    return p + (float)j;
+#endif
     const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
-    const f32x4 zj = *(const f32x4*)(zp + lane * 4);
-    const float d = wave_sum(p.x * zj.x + p.y * zj.y + p.z * zj.z + p.w * zj.w);
-    if (lane == 0) cosv[r * 32 + j] = d / pn;
+    return *(const f32x4*)(zp + lane * 4);
+  };
+  for (int j0 = 0; j0 < nt; j0 += SC_ZCH) {
+    f32x4 zc[SC_ZCH];
+#pragma unroll
+    for (int u = 0; u < SC_ZCH; ++u) zc[u] = zrow(min(j0 + u, nt - 1));
+#pragma unroll
+    for (int u = 0; u < SC_ZCH; ++u)
+      if (j0 + u < nt) {
+        const f32x4 zj = zc[u];
+        const float d = wave_sum(p.x * zj.x + p.y * zj.y + p.z * zj.z + p.w * zj.w);
+        if (lane == 0) cosv[r * 32 + j0 + u] = d / pn;
+      }
   }
   __builtin_amdgcn_wave_barrier();
   if (a.scores_out && lane < nt && m0 + r < n) a.scores_out[(size_t)(m0 + r) * nt + lane] = cosv[r * 32 + lane] * inv_tau;
@@ -298,12 +317,17 @@ __device__ __forceinline__ f32x4 score_row(const ScorerArgs& a, int m0, int n, i
   __builtin_amdgcn_wave_barrier();
   f32x4 gs = {0, 0, 0, 0};
   float gc = 0.0f;
-  for (int j = 0; j < nt; ++j) {
-    const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
-    const f32x4 zj = *(const f32x4*)(zp + lane * 4);
-    const float gj = coef[r * 32 + j];
-    gs += gj * zj;
-    gc += gj * cosv[r * 32 + j];
+  for (int j0 = 0; j0 < nt; j0 += SC_ZCH) {
+    f32x4 zc[SC_ZCH];
+#pragma unroll
+    for (int u = 0; u < SC_ZCH; ++u) zc[u] = zrow(min(j0 + u, nt - 1));
+#pragma unroll
+    for (int u = 0; u < SC_ZCH; ++u)
+      if (j0 + u < nt) {
+        const float gj = coef[r * 32 + j0 + u];
+        gs += gj * zc[u];
+        gc += gj * cosv[r * 32 + j0 + u];
+      }
   }
   const f32x4 dp = gs / pn - (gc / (pn * pn)) * p;
   if (lane == 0 && a.loss_out && m0 + r < n) a.loss_out[m0 + r] = lossv;
@@ -424,75 +448,92 @@ __global__ __launch_bounds__(64 * SC_NW, 4) void scorer_kernel(ScorerArgs a) {
 #endif
 static __device__ int g_scorer_range_flag;
 
+#ifndef SC16_ROWS
+#define SC16_ROWS 32                  // sentences per workgroup of the f16x3 kernel (64 builds too: see the note at the kernel)
+#endif
+#define SC16_RT (SC16_ROWS / 16)      // 16-row tiles
+#define SC16_RPW (SC16_ROWS / SC_NW)  // rows per wave in the row-wise phases
+#define SC16_BUF (SC16_ROWS * SC_LD)
 template <int K, int N, bool FWD, int ACT, bool OUT_F32>
 __device__ __forceinline__ void tile_linear16(float* Xs, const float* __restrict__ W, const float* __restrict__ bias,
-                                              float unscale, uint32_t& mask, const float* rowinv, int& bad) {
+                                              float unscale, uint32_t (&mask)[SC16_RT / 2], const float* rowinv, int& bad) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r16 = lane & 15, g = lane >> 4;
   constexpr int DS = K / 32;            // double k-steps
   constexpr int NFT = N / 16 / SC_NW;   // 16-feature tiles per wave: tile t = wave + 8 i
+  constexpr int RT = SC16_RT;
   static_assert(NFT >= 1 && N % (16 * SC_NW) == 0 && K % 32 == 0, "layer shape");
   constexpr int R = SC16_RING;          // W ring depth in double steps
   static_assert(DS % R == 0, "ring");
   const unsigned wl = (unsigned)(((g >> 1) * 128 + 32 * (g & 1) + r16) * 16);
   const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, N * K * 4, 0x00020000);
-  auto wfetch = [&](int d, f32x4 (&dst)[NFT][2]) {
+  // A wave's NFT feature tiles go through the matrix cores G at a time (all their accumulators stay in registers until the
+  // layer's in-place write): the W ring and the fragments in use are those of G tiles, not of NFT (64 rows x 4 tiles would
+  // not fit 256 registers).  The ring runs on from one group into the next, so only a layer's first fragments wait for L2.
+  constexpr int G = NFT > 2 ? 2 : NFT, NG = NFT / G, TOT = NG * DS;
+  static_assert(NFT % G == 0, "groups");
+  auto wfetch = [&](int s, f32x4 (&dst)[G][2]) {   // s = group * DS + double step
+    const int ig = s / DS, d = s % DS;
 #pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-      const int t = wave + SC_NW * i;
+    for (int i = 0; i < G; ++i) {
+      const int t = wave + SC_NW * (ig * G + i);
       const int off = (t >> 1) * (K / 16) * 2048 + d * 4096 + (t & 1) * 256;  // wave-uniform
       dst[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl, off, 0));
       dst[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, wl + 1024, off, 0));
     }
   };
-  f32x4 ring[R][NFT][2];
+  f32x4 ring[R][G][2];
 #pragma unroll
   for (int j = 0; j < R; ++j) wfetch(j, ring[j]);
-  f32x4 acc[NFT][2];
+  f32x4 acc[NFT][RT];
 #pragma unroll
-  for (int i = 0; i < NFT; ++i) {
-    acc[i][0] = (f32x4){0, 0, 0, 0};
-    acc[i][1] = (f32x4){0, 0, 0, 0};
-  }
+  for (int i = 0; i < NFT; ++i)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[i][rt] = (f32x4){0, 0, 0, 0};
   const float* xb = Xs + r16 * SC_LD + 4 * g;
 #pragma unroll
-  for (int d = 0; d < DS; ++d) {
-    f32x4 wf[NFT][2];
+  for (int s = 0; s < TOT; ++s) {
+    const int ig = s / DS, d = s % DS;
+    f32x4 (&wf)[G][2] = ring[s % R];
+    h8 xh[RT], xl[RT];
 #pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-      wf[i][0] = ring[d % R][i][0];
-      wf[i][1] = ring[d % R][i][1];
+    for (int rt = 0; rt < RT; ++rt) {
+      xh[rt] = as_h8(*(const f32x4*)(xb + 16 * rt * SC_LD + 16 * d));
+      xl[rt] = as_h8(*(const f32x4*)(xb + 16 * rt * SC_LD + SH_LO + 16 * d));
     }
-    if (d + R < DS) wfetch(d + R, ring[d % R]);
-    const h8 x0h = as_h8(*(const f32x4*)(xb + 16 * d)), x0l = as_h8(*(const f32x4*)(xb + SH_LO + 16 * d));
-    const h8 x1h = as_h8(*(const f32x4*)(xb + 16 * SC_LD + 16 * d)), x1l = as_h8(*(const f32x4*)(xb + 16 * SC_LD + SH_LO + 16 * d));
+    // (per accumulator the order is hi.hi, lo.hi, hi.lo, as in the 32-row form: a row's result does not depend on the tile height)
 #pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-      acc[i][0] = mfma16x32h(as_h8(wf[i][0]), x0h, acc[i][0]);
-      acc[i][1] = mfma16x32h(as_h8(wf[i][0]), x1h, acc[i][1]);
-    }
+    for (int i = 0; i < G; ++i)
 #pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-      acc[i][0] = mfma16x32h(as_h8(wf[i][1]), x0h, acc[i][0]);
-      acc[i][1] = mfma16x32h(as_h8(wf[i][1]), x1h, acc[i][1]);
-    }
+      for (int rt = 0; rt < RT; ++rt) acc[ig * G + i][rt] = mfma16x32h(as_h8(wf[i][0]), xh[rt], acc[ig * G + i][rt]);
 #pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-      acc[i][0] = mfma16x32h(as_h8(wf[i][0]), x0l, acc[i][0]);
-      acc[i][1] = mfma16x32h(as_h8(wf[i][0]), x1l, acc[i][1]);
-    }
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[ig * G + i][rt] = mfma16x32h(as_h8(wf[i][1]), xh[rt], acc[ig * G + i][rt]);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[ig * G + i][rt] = mfma16x32h(as_h8(wf[i][0]), xl[rt], acc[ig * G + i][rt]);
+    // the slot is refilled behind its own MFMAs (no second copy of the fragments)
+    if (s + R < TOT) wfetch(s + R, ring[s % R]);
+#ifndef SC16_NOSB
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   __syncthreads();  // every wave has read its last input fragment: the layer is written IN PLACE
 #pragma unroll
   for (int i = 0; i < NFT; ++i)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int f0 = 16 * (wave + SC_NW * i) + 4 * g;
       const int row = 16 * rt + r16;
+      float* yrow = Xs + row * SC_LD;
       f32x4 v = acc[i][rt] * unscale;
       if (FWD) v += *(const f32x4*)(bias + f0);
       if (ACT != ACT_NONE) {
-        const int sh = (2 * i + rt) * 4;
+        // mask word rt >> 1 holds the nibbles of row tiles 2 (rt >> 1), 2 (rt >> 1) + 1: (2 i + (rt & 1)) * 4, NFT <= 4
+        const int sh = (2 * i + (rt & 1)) * 4;
+        uint32_t& mk = mask[rt >> 1];
         if (FWD) {
           uint32_t nib = 0;
 #pragma unroll
@@ -501,57 +542,65 @@ __device__ __forceinline__ void tile_linear16(float* Xs, const float* __restrict
             nib |= (on ? 1u : 0u) << j;
             v[j] = on ? v[j] : (ACT == ACT_RELU ? 0.0f : 0.2f * v[j]);
           }
-          mask |= nib << sh;
+          mk |= nib << sh;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const bool on = (mask >> (sh + j)) & 1u;
+            const bool on = (mk >> (sh + j)) & 1u;
             v[j] = on ? v[j] : (ACT == ACT_RELU ? 0.0f : 0.2f * v[j]);
           }
         }
       }
       if (OUT_F32) {
         if (!FWD) v = v * rowinv[row];
-        *(f32x4*)(Xs + row * SC_LD + f0) = v;
+        *(f32x4*)(yrow + f0) = v;
       } else {
         const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         bad |= !(m <= 65504.0f);
         h4 hi, lo;
         split_f16(v, hi, lo);
-        *(h4*)(Xs + row * SC_LD + (f0 >> 1)) = hi;
-        *(h4*)(Xs + row * SC_LD + SH_LO + (f0 >> 1)) = lo;
+        *(h4*)(yrow + (f0 >> 1)) = hi;
+        *(h4*)(yrow + SH_LO + (f0 >> 1)) = lo;
       }
     }
+  // (the range test is evaluated HERE: left alone, the compiler sinks these maxima to the kernel's end, where `bad` is
+  // read, and keeps every layer's outputs alive for them - in scratch memory)
+  asm volatile("" : "+v"(bad));
 }
 
-#define SC16_LDS_BYTES ((SC_BUF + 32 * 32 * 2 + 32) * 4)
+#define SC16_LDS_BYTES ((SC16_BUF + SC16_ROWS * 32 * 2 + SC16_ROWS) * 4)
 
-// Two waves per SIMD = 256 registers per lane: one workgroup per CU.  With the 128-register budget of two workgroups per CU
-// (launch bound 4) the EDIT instantiation spilled (8 vector registers to scratch, 150 scalar registers to vector lanes) and
-// returned WRONG gradients on ~1 % of the rows - lanes 48..63 of one component of dP, only in the last row of a wave's row
-// loop, only in workgroups that started as the second one on a CU, different from run to run
-// (tools/check_scorer_determinism.py; the forward-only instantiation, which does not spill, never did).  Without spills the
-// kernel is bit-reproducible; the whole bench is 0.7 % slower than with two workgroups per CU, batch 256 is 4 % faster
-// (profiles/r03_scorer_f16x3.txt).  tests/test_gpu_kernels.py::test_scorer_edit_step_is_bit_reproducible guards it.
+// Registers.  The first build of this kernel for two workgroups per CU (128 registers) spilled 8 vector registers to scratch
+// and returned WRONG gradients on ~1 % of the rows (lanes 48..63 of one component of dP, only in workgroups that started as
+// the second one on a CU, different from run to run: tools/check_scorer_determinism.py), so it ran as one workgroup per CU
+// at 159 registers.  The cause of the pressure was not the products: every layer's epilogue tests its outputs against the
+// f16 range (`bad`), and the compiler SANK those maxima to the end of the kernel, where `bad` is read, keeping every layer's
+// outputs alive for them.  With the test pinned behind each layer (the asm statement at the end of tile_linear16) the
+// forward instantiation needs 90 registers and the edit step 109 - no spill at the 128 of two workgroups per CU, which
+// hide each other's layer-start and score-phase latencies: 1472 -> 1198 us per launch at 98 304 sentences, same box
+// (tools/bench_scorer_step.py).  A 64-row tile (SC16_ROWS 64: one workgroup per CU, half the weight stream out of L2, 224 -
+// 255 registers) measured the same 1.21 ms, and streaming the unit vectors through register buffers one row ahead bought it
+// nothing more: the two-workgroup form is the simplest of the three.  tests/test_gpu_kernels.py::
+// test_scorer_edit_step_is_bit_reproducible guards the result.
 #ifndef SC16_WAVES_PER_EU
-#define SC16_WAVES_PER_EU 2
+#define SC16_WAVES_PER_EU (SC16_ROWS > 32 ? 2 : 4)
 #endif
 template <bool EDIT>
 __global__ __launch_bounds__(64 * SC_NW, SC16_WAVES_PER_EU) void scorer16_kernel(ScorerArgs a) {
   extern __shared__ __align__(16) float smem[];
-  float* buf = smem;                 // [32][SC_LD]: the one activation buffer
-  float* cosv = smem + SC_BUF;       // [32][32]
-  float* coef = cosv + 32 * 32;      // [32][32]
-  float* rowinv = coef + 32 * 32;    // [32]
+  float* buf = smem;                       // [SC16_ROWS][SC_LD]: the one activation buffer
+  float* cosv = smem + SC16_BUF;           // [SC16_ROWS][32]
+  float* coef = cosv + SC16_ROWS * 32;     // [SC16_ROWS][32]
+  float* rowinv = coef + SC16_ROWS * 32;   // [SC16_ROWS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n;
-  const int m0 = blockIdx.x * SC_ROWS;
+  const int m0 = blockIdx.x * SC16_ROWS;
   if (m0 >= n) return;
   const float* xin = EDIT ? a.latent : a.x;
   int bad = 0;
-  // latent tile -> split halves (32 rows x 64 float4 = 2048)
+  // latent tile -> split halves (SC16_ROWS rows x 64 float4)
 #pragma unroll
-  for (int i = 0; i < 2048 / (64 * SC_NW); ++i) {
+  for (int i = 0; i < SC16_ROWS * 64 / (64 * SC_NW); ++i) {
     const int f = tid + i * 64 * SC_NW;
     const int r = f >> 6, c4 = f & 63;
     const f32x4 v = *(const f32x4*)(xin + (size_t)min(m0 + r, n - 1) * 256 + c4 * 4);
@@ -564,7 +613,7 @@ __global__ __launch_bounds__(64 * SC_NW, SC16_WAVES_PER_EU) void scorer16_kernel
   }
   __syncthreads();
   const float* us = a.w.unscale;
-  uint32_t m1 = 0, m2 = 0, mq = 0, none = 0;
+  uint32_t m1[SC16_RT / 2] = {}, m2[SC16_RT / 2] = {}, mq[SC16_RT / 2] = {}, none[SC16_RT / 2] = {};
   const bool simplest = EDIT && (a.flags & ST_F_SIMPLEST);
   tile_linear16<256, 512, true, ACT_RELU, false>(buf, a.w.s1_w, a.w.s1_b, us[0], m1, nullptr, bad);
   __syncthreads();
@@ -577,8 +626,8 @@ __global__ __launch_bounds__(64 * SC_NW, SC16_WAVES_PER_EU) void scorer16_kernel
   __syncthreads();
 
   if (!EDIT) {
-    for (int rr = 0; rr < SC_RPW; ++rr) {
-      const int r = wave * SC_RPW + rr;
+    for (int rr = 0; rr < SC16_RPW; ++rr) {
+      const int r = wave * SC16_RPW + rr;
       if (m0 + r >= n) continue;
       f32x4 v = *(const f32x4*)(buf + r * SC_LD + lane * 4);
       if (a.unit) {
@@ -599,11 +648,8 @@ __global__ __launch_bounds__(64 * SC_NW, SC16_WAVES_PER_EU) void scorer16_kernel
     // ---- scores, loss, dL/dp: p as f32 in buf[., 0:256]; dP goes back as scaled split halves ----
     const int np = a.n_pos, nn = a.n_neg, nt = np + nn;
     const float inv_tau = 1.0f / a.tau;
-    for (int rr = 0; rr < SC_RPW; ++rr) {
-      const int r = wave * SC_RPW + rr;
-      const int b = min(m0 + r, n - 1);
-      const f32x4 p = *(const f32x4*)(buf + r * SC_LD + lane * 4);
-      const f32x4 dp = score_row(a, m0, n, r, b, p, cosv, coef, np, nn, nt, inv_tau);
+    // dP row -> scaled split halves in the activation buffer
+    auto finish_row = [&](int r, f32x4 dp) {
       const float mx = wave_max(fmaxf(fmaxf(fabsf(dp.x), fabsf(dp.y)), fmaxf(fabsf(dp.z), fabsf(dp.w))));
       // power of two that brings the row's largest |dP| into [512, 1024); 1 for a zero / non-finite row
       const int ex = (int)((__float_as_uint(mx) >> 23) & 255u) - 127;
@@ -617,6 +663,12 @@ __global__ __launch_bounds__(64 * SC_NW, SC16_WAVES_PER_EU) void scorer16_kernel
       split_f16(v, hi, lo);
       *(h4*)(buf + r * SC_LD + lane * 2) = hi;
       *(h4*)(buf + r * SC_LD + SH_LO + lane * 2) = lo;
+    };
+    for (int rr = 0; rr < SC16_RPW; ++rr) {
+      const int r = wave * SC16_RPW + rr;
+      const int b = min(m0 + r, n - 1);
+      const f32x4 p = *(const f32x4*)(buf + r * SC_LD + lane * 4);
+      finish_row(r, score_row(a, m0, n, r, b, p, cosv, coef, np, nn, nt, inv_tau));
     }
     __syncthreads();
     // ---- backward to the latent ----
@@ -632,8 +684,8 @@ __global__ __launch_bounds__(64 * SC_NW, SC16_WAVES_PER_EU) void scorer16_kernel
     __syncthreads();
     tile_linear16<512, 256, false, BWD_NONE, true>(buf, a.w.s1_wt, nullptr, us[0], none, rowinv, bad);
     __syncthreads();
-    for (int rr = 0; rr < SC_RPW; ++rr) {
-      const int r = wave * SC_RPW + rr;
+    for (int rr = 0; rr < SC16_RPW; ++rr) {
+      const int r = wave * SC16_RPW + rr;
       const int b = m0 + r;
       if (b >= n) continue;
       const f32x4 g = *(const f32x4*)(buf + r * SC_LD + lane * 4);
@@ -661,7 +713,7 @@ template <bool EDIT>
 static int launch_scorer(const ScorerArgs& a, hipStream_t st) {
   if (a.w.gemm_format == ST_GEMM_F16X3) {
     ST_ENSURE_LDS((scorer16_kernel<EDIT>), SC16_LDS_BYTES);
-    hipLaunchKernelGGL(scorer16_kernel<EDIT>, dim3((a.n + SC_ROWS - 1) / SC_ROWS), dim3(64 * SC_NW), SC16_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(scorer16_kernel<EDIT>, dim3((a.n + SC16_ROWS - 1) / SC16_ROWS), dim3(64 * SC_NW), SC16_LDS_BYTES, st, a);
     ST_LAUNCH_CHECK();
     return ST_OK;
   }

@@ -51,6 +51,9 @@ for fmt in ("f16x3", "f32"):
               "per column:", [(int((s0[:, c] != s1[:, c]).sum())) for c in range(6)])
         g0, g1 = outs[0][1][0], outs[1][1][0]
         rows = (g0 != g1).any(1).nonzero().flatten()
+        if rows.numel() == 0:
+            print("first-step gradients of the two runs are bit-identical in every row")
+            continue
         import collections
         tiles = collections.Counter((rows // 32).tolist())
         print("tiles with differing rows:", len(tiles), "min tile", min(tiles), "max tile", max(tiles), "rows-in-tile histogram:",
