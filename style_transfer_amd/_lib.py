@@ -20,7 +20,7 @@ ST_DEC_NO_L0_TABLE = 4
 ST_PROF_OFF, ST_PROF_GENERATOR, ST_PROF_HALF_LAYER = 0, 1, 2
 ST_GEMM_F32, ST_GEMM_F16X3 = 0, 1
 GEMM_FORMATS = {"f32": ST_GEMM_F32, "f16x3": ST_GEMM_F16X3}
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 fp = C.c_void_p  # device pointers travel as integers
 

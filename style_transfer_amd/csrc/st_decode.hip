@@ -16,7 +16,7 @@ void st_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* st_last_error(void) { return g_err; }
-extern "C" int st_abi_version(void) { return 7; }
+extern "C" int st_abi_version(void) { return 8; }
 
 // ---- optional in-library timing of the dominant kernel (generator GEMM + argmax) -----------------
 #include <vector>
