@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __res
 // Operand format of the similarity GEMMs (ST_GEMM_*).  F16X3 (default): unit rows lie in [-1, 1] and dS in [-1, 1], the
 // ideal domain of the hi + lo split (f32-grade: ~2^-22 per term), and every product of the block runs on the f16 MFMA.
 static int g_sl_format = ST_GEMM_F16X3;
-static int g_sl_fused = getenv("ST_AB_ENABLE") && getenv("ST_AB_SIMLOSS_CHUNKED") ? 0 : 1;  // A/B: the round-2 chunked backward
+int g_sl_fused = getenv("ST_AB_ENABLE") && getenv("ST_AB_SIMLOSS_CHUNKED") ? 0 : 1;  // A/B: 0 = the round-2 chunked backward
 extern "C" int st_simloss_format(int gemm_format) {
   const int prev = g_sl_format;
   if (gemm_format == ST_GEMM_F32 || gemm_format == ST_GEMM_F16X3) g_sl_format = gemm_format;
