@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ em
     atomicAdd(work + 1, (unsigned long long)n * (unsigned long long)(pos + 1));
     if (pos == 0) atomicAdd(work + 2, (unsigned long long)n);
   }
+  if (!x) return;  // the first layer's half-layer kernel computes the rows itself (OFArgs.emb)
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const int lane = threadIdx.x & 63;
@@ -128,7 +129,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ em
   tok = min(max(tok, 0), vocab - 1);
   const f32x4 e = *(const f32x4*)(emb + (size_t)tok * 256 + lane * 4);
   const f32x4 p = *(const f32x4*)(pe + (size_t)pos * 256 + lane * 4);
-  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = fmaf(e[q], 16.0f, p[q]);  // (the half-layer kernel's EMB form repeats exactly this)
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -809,8 +813,12 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   for (int pos = 0; pos < T && n_bound > 0; ++pos) {
     const int* idx = ws.idx[cur];
     const int* n_dev = ws.cnt + cur;
-    hipLaunchKernelGGL(embed_kernel, dim3((n_bound + 3) / 4), dim3(256), 0, st, w->emb, w->pe, idx, n_dev,
-                       ws.cnt + (cur ^ 1), ws.cnt + 2, out_ids, T, pos, bos, w->vocab, ws.x, work);
+    // With the first layer on the table nothing reads the embedded rows but that layer's half-layer kernel (its residual):
+    // it computes them itself from the tokens, and the embed kernel only keeps the step's counters (1 KB per row less
+    // written and read).  Below RP_TAIL_MIN_ROWS the unfused chain runs and x is written as before.
+    const bool emb_in_tail = use_tab && w->gemm_format == ST_GEMM_F16X3 && n_bound >= RP_TAIL_MIN_ROWS && rp_tail_shape16 && !rp_no_emb_in_tail;
+    hipLaunchKernelGGL(embed_kernel, dim3(emb_in_tail ? 1 : (n_bound + 3) / 4), dim3(256), 0, st, w->emb, w->pe, idx, n_dev,
+                       ws.cnt + (cur ^ 1), ws.cnt + 2, out_ids, T, pos, bos, w->vocab, emb_in_tail ? (float*)nullptr : ws.x, work);
     ST_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
       const StDecLayer& y = w->layer[l];
@@ -858,6 +866,9 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       of.att = ws.att; of.n_dev = n_dev; of.n_host = n_bound; of.wo = y.wo; of.bo = y.bo; of.x = ws.x;
       of.cconst = ws.cc + (size_t)l * B * 256; of.idx = idx; of.ln_a = y.ln2_a; of.ln_b = y.ln2_b;
       of.w1 = y.w1; of.b1 = y.b1; of.h = ws.h; of.d_ff = w->d_ff; of.w2 = y.w2; of.b2 = y.b2;
+      if (l == 0 && emb_in_tail) {
+        of.emb = w->emb; of.pe_row = w->pe + (size_t)pos * 256; of.ys = out_ids; of.T = T; of.pos = pos; of.bos = bos; of.vocab = w->vocab;
+      }
       if (w->gemm_format == ST_GEMM_F16X3 && n_bound >= RP_TAIL_MIN_ROWS) {
         ProfPair pt;
         if (g_prof_on == ST_PROF_HALF_LAYER)

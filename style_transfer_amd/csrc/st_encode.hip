@@ -15,7 +15,10 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
   const int t = min(max(tok[r], 0), vocab - 1);
   const f32x4 e = *(const f32x4*)(emb + (size_t)t * 256 + lane * 4);
   const f32x4 p = *(const f32x4*)(pe + (size_t)pos[r] * 256 + lane * 4);
-  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = fmaf(e[q], 16.0f, p[q]);  // (rp_layer_tail16_kernel<1, 2> repeats exactly this)
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = v;
 }
 
 // Full (non-causal) self-attention inside each sentence of 17..64 tokens (amazon): block = sentence, wave = head, on
@@ -698,8 +701,15 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     hipLaunchKernelGGL(enc_window_kernel, dim3((n_sent + 1 + 255) / 256), dim3(256), 0, st, sent_off, n_sent, win, n_win, first_sent);
   }
   hipLaunchKernelGGL(enc_check_len_kernel, dim3((n_sent + 255) / 256), dim3(256), 0, st, sent_off, n_sent, max_sent_len, n_rows, range_flag);
-  hipLaunchKernelGGL(enc_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->emb, w->pe, tokens, tok_pos, R, w->vocab, x);
-  ST_LAUNCH_CHECK();
+  // With the first layer on the (token, position) table nothing reads the embedded rows but that layer's half-layer kernel
+  // (its residual), which then computes them itself: no embed kernel, 1 KB per row less written and read.
+  const bool emb_in_tail = fused && w->l0_table != nullptr && w->l0_table_len >= max_sent_len && w->gemm_format == ST_GEMM_F16X3 &&
+                           max_sent_len <= RP_TAIL_PE_ROWS && w->pe_rows >= RP_TAIL_PE_ROWS && R >= RP_TAIL_MIN_ROWS && rp_tail_shape16 &&
+                           !rp_no_emb_in_tail;
+  if (!emb_in_tail) {
+    hipLaunchKernelGGL(enc_embed_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->emb, w->pe, tokens, tok_pos, R, w->vocab, x);
+    ST_LAUNCH_CHECK();
+  }
   for (int l = 0; l < w->n_layers; ++l) {
     const StEncLayer& y = w->layer[l];
     ST_CHECK_ARG(y.ln0_a && y.ln0_b && y.wqkv && y.bqkv && y.wo && y.bo && y.ln1_a && y.ln1_b && y.w1 && y.b1 && y.w2 && y.b2,
@@ -748,6 +758,9 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
     of.fmt = w->gemm_format; of.range_flag = range_flag;
     of.att = att; of.n_host = R; of.wo = y.wo; of.bo = y.bo; of.x = x; of.ln_a = y.ln1_a; of.ln_b = y.ln1_b;
     of.w1 = y.w1; of.b1 = y.b1; of.h = h; of.d_ff = w->d_ff; of.w2 = y.w2; of.b2 = y.b2;
+    if (l == 0 && emb_in_tail) {
+      of.emb = w->emb; of.pe = w->pe; of.tokens = tokens; of.tok_pos = tok_pos; of.vocab = w->vocab;
+    }
     if (w->gemm_format == ST_GEMM_F16X3 && R >= RP_TAIL_MIN_ROWS) {
       ProfPair pt;
       if (g_prof_on == ST_PROF_HALF_LAYER) ST_TRY(prof_begin(&pt, 2.0 * 256.0 * (256.0 + 2.0 * (double)w->d_ff), nullptr, R, st));
@@ -806,7 +819,10 @@ __global__ __launch_bounds__(256) void enc_l0_embed_kernel(const float* __restri
   const int tok = (int)(r / positions), pos = (int)(r % positions);
   const f32x4 e = *(const f32x4*)(emb + (size_t)tok * 256 + lane * 4);
   const f32x4 p = *(const f32x4*)(pe + (size_t)pos * 256 + lane * 4);
-  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;   // exactly enc_embed_kernel's expression
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = fmaf(e[q], 16.0f, p[q]);   // exactly enc_embed_kernel's expression
+  *(f32x4*)(x + (size_t)r * 256 + lane * 4) = v;
 }
 
 extern "C" int st_encode_build_l0_table(const StEncoderWeights* w, int positions, float* table, void* scratch,

@@ -64,6 +64,7 @@ ST_RP_SWITCH(rp_tail_shape16, 1);     // ST_AB_TAIL32: the round-1 32x32x16 half
 ST_RP_SWITCH(rp_tail_min_rows, 64);   // ST_AB_TAIL_MIN_ROWS=<n>
 ST_RP_SWITCH(rp_enc_unfused, 0);      // ST_AB_ENC_UNFUSED: encoder QKV and attention as two kernels
 ST_RP_SWITCH(rp_dec_fused, 0);        // ST_AB_DEC_FUSED: decode QKV + attention in one kernel (measured negative, st_decode.hip)
+ST_RP_SWITCH(rp_no_emb_in_tail, 0);   // ST_AB_EMBED_KERNEL: the decode step's embed kernel writes x for the first layer's half-layer kernel
 #undef ST_RP_SWITCH
 static inline void rp_ab_env() {
   static const bool done = [] {
@@ -78,6 +79,7 @@ static inline void rp_ab_env() {
     if (getenv("ST_AB_TAIL_MIN_ROWS")) rp_tail_min_rows = atoi(getenv("ST_AB_TAIL_MIN_ROWS"));
     if (getenv("ST_AB_ENC_UNFUSED")) rp_enc_unfused = 1;
     if (getenv("ST_AB_DEC_FUSED")) rp_dec_fused = 1;
+    if (getenv("ST_AB_EMBED_KERNEL")) rp_no_emb_in_tail = 1;
     return true;
   }();
   (void)done;
@@ -1925,7 +1927,19 @@ struct OFArgs {
   int fmt;                       // operand format of wo / w1 / w2 (ST_GEMM_F32 / ST_GEMM_F16X3)
   const float *w2, *b2;          // packed [256,d_ff], [256]   (rp_layer_tail_kernel only)
   int* range_flag;               // f16x3: set to 1 when an operand leaves the f16 range (null = unchecked)
+  // rp_layer_tail16_kernel<SITE, true>: the residual is the decode step's EMBEDDING, computed here from the token the row's
+  // job emitted last (emb[token] * 16 + pe[pos], model.py:126-133) instead of read from x (x is still written)
+  const float* emb;              // [vocab,256]
+  const float* pe_row;           // pe + pos * 256
+  const int32_t* ys;             // [jobs,T] emitted ids
+  int T, pos, bos, vocab;
+  // rp_layer_tail16_kernel<SITE, 2>: the same for the encoder's first layer, whose rows carry their own token and position
+  // (every position < RP_TAIL_PE_ROWS: the first rows of pe are kept in LDS)
+  const int32_t* tokens;         // [n]
+  const int32_t* tok_pos;        // [n]
+  const float* pe;               // [>= RP_TAIL_PE_ROWS, 256]
 };
+#define RP_TAIL_PE_ROWS 16
 
 template <bool H = false>
 __global__ __launch_bounds__(256, 2) void rp_oproj_ffn1_kernel(OFArgs a) {
@@ -2142,7 +2156,8 @@ static int launch_oproj_ffn1(const OFArgs& a, int n_bound, hipStream_t st) {
 // as packed halves (ds_write_b64) in exactly the layout the FFN2 A fragments are read from.
 // HBM traffic per row: att + x in, x out (3 KiB) instead of 13 KiB for the unfused chain.
 // ------------------------------------------------------------------------------------------------
-#define RP_TAIL_LDS ((2 * 64 * ST_LDA + 64) * 4)  /* two panels + the cross-attention index of the next panel's rows */
+#define RP_TAIL_LDS ((2 * 64 * ST_LDA + 128) * 4)  /* two panels + the cross-attention index and the token of the next panel's rows */
+#define RP_TAIL_LDS_ENC (RP_TAIL_LDS + (128 + RP_TAIL_PE_ROWS * ST_LDA) * 4)  /* + the rows' positions and the first rows of pe */
 #define RP_TAIL_MIN_ROWS rp_tail_min_rows
 #define RP_TAIL_MMA6(ACC0, ACC1, A0H, A0L, A1H, A1L, BH, BL) \
   ACC0 = mfma16h(A0H, BH, ACC0);                             \
@@ -2747,12 +2762,19 @@ static int launch_layer_tail32(const OFArgs& a, int n_bound, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // SITE only names the instantiation (0 = decoder, i.e. the edit loop; 1 = encoder, i.e. set-up), so that profiles and
 // counter passes can tell the two apart (tools/summarize_pmc.py): the code is the same.
-template <int SITE = 0>
+// EMB != 0: the residual rows are embeddings computed in place (OFArgs.emb ..), so that no embed kernel writes x for this
+// launch: 1 = decode step (one position, token = the job's last id), 2 = encoder (a token and a position per row)
+template <int SITE = 0, int EMB = 0>
 __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* P1 = smem;
   float* P2 = smem + 64 * ST_LDA;
   int* sIdx = (int*)(smem + 2 * 64 * ST_LDA);
+  int* sTok = sIdx + 64;
+  int* sPos = sTok + 64;                   // EMB == 2 only (RP_TAIL_LDS_ENC): [2][64], by panel parity - the positions are
+                                           // read where the residual is ADDED, when wave 0 may already be staging the next panel
+  float* sPe = (float*)(sPos + 128);       // [RP_TAIL_PE_ROWS][ST_LDA]
+  int par = 0;                             // parity of this workgroup's current panel
   const int n = a.n_dev ? *a.n_dev : a.n_host;
   const int mstride = gridDim.x * 64;
   int m0 = blockIdx.x * 64;
@@ -2789,13 +2811,27 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
     }
   };
   f32x4 ax[2][4], px[2][4], pc[2][4];  // [feature tile][row tile]
-  auto idx_stage = [&](int mb) {
-    if (a.cconst && tid < 64) sIdx[tid] = a.idx[min(mb + tid, n - 1)];
+  auto idx_stage = [&](int mb, int stage_par) {
+    if (EMB == 2) {
+      if (tid < 64) {
+        const int r = min(mb + tid, n - 1);
+        sTok[tid] = min(max(a.tokens[r], 0), a.vocab - 1);
+        sPos[64 * stage_par + tid] = min(max(a.tok_pos[r], 0), RP_TAIL_PE_ROWS - 1);
+      }
+    } else if ((a.cconst || EMB) && tid < 64) {
+      const int s = a.idx[min(mb + tid, n - 1)];
+      sIdx[tid] = s;
+      if (EMB) {
+        const int tok = a.pos == 0 ? a.bos : a.ys[(size_t)s * a.T + a.pos - 1];
+        sTok[tid] = min(max(tok, 0), a.vocab - 1);
+      }
+    }
   };
   auto resid_load = [&](int mb) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const float* xr = a.x + (size_t)min(mb + 16 * rt + r16, n - 1) * 256 + fcol;
+      const float* xr = EMB ? a.emb + (size_t)sTok[16 * rt + r16] * 256 + fcol
+                            : a.x + (size_t)min(mb + 16 * rt + r16, n - 1) * 256 + fcol;
       px[0][rt] = *(const f32x4*)xr;
       px[1][rt] = *(const f32x4*)(xr + 16);
     }
@@ -2812,7 +2848,14 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
     }
   };
   att_load(m0);
-  idx_stage(m0);
+  idx_stage(m0, 0);
+  if (EMB == 2) {
+#pragma unroll
+    for (int i = 0; i < RP_TAIL_PE_ROWS * 64 / 512; ++i) {
+      const int f = tid + i * 512;
+      *(f32x4*)(sPe + (f >> 6) * ST_LDA + (f & 63) * 4) = *(const f32x4*)(a.pe + (size_t)(f >> 6) * 256 + (f & 63) * 4);
+    }
+  }
   f32x4 b1n[2];  // FFN1 bias of this lane's 8 hidden units in the coming chunk
   auto b1_fetch = [&](int c) {
     b1n[0] = *(const f32x4*)(a.b1 + (c * 8 + wave) * 32 + 4 * g);
@@ -2914,10 +2957,21 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) ax[ft][rt] += px[ft][rt] + pc[ft][rt];
+    for (int rt = 0; rt < 4; ++rt) {
+      if (EMB) {  // x = emb[token] * 16 + pe[pos], the embed kernel's arithmetic
+        const f32x4 pev = EMB == 2 ? *(const f32x4*)(sPe + sPos[64 * par + 16 * rt + r16] * ST_LDA + fcol + 16 * ft)
+                                   : *(const f32x4*)(a.pe_row + fcol + 16 * ft);
+        f32x4 xv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = fmaf(px[ft][rt][q], 16.0f, pev[q]);
+        ax[ft][rt] += xv + pc[ft][rt];
+      } else {
+        ax[ft][rt] += px[ft][rt] + pc[ft][rt];
+      }
+    }
   TSTAMP(2);
   b1_fetch(0);
-  if (m0 + mstride < n) idx_stage(m0 + mstride);  // read by resid_load in the last chunk, many barriers from here
+  if (m0 + mstride < n) idx_stage(m0 + mstride, par ^ 1);  // read by resid_load in the last chunk, many barriers from here
   __syncthreads();  // every wave is done reading the attention panel
   TSTAMP(3);
   // (the LayerNorm gains are fetched per panel - L2 hits, the address hangs on the opaque lane - instead of living in 8
@@ -3005,6 +3059,7 @@ __global__ __launch_bounds__(512, 2) void rp_layer_tail16_kernel(OFArgs a) {
   }
   TSTAMP(30);
   m0 += mstride;
+  par ^= 1;
   if (m0 >= n) break;
   att_store();
   TSTAMP(36);
@@ -3036,9 +3091,10 @@ static int launch_layer_tail64(const OFArgs& a, int n_bound, hipStream_t st) {
   return ST_OK;
 }
 
-template <int SITE = 0>
+template <int SITE = 0, int EMB = 0>
 static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
-  ST_ENSURE_LDS((rp_layer_tail16_kernel<SITE>), RP_TAIL_LDS);
+  constexpr int LDS = EMB == 2 ? RP_TAIL_LDS_ENC : RP_TAIL_LDS;
+  ST_ENSURE_LDS((rp_layer_tail16_kernel<SITE, EMB>), LDS);
   if (n_bound <= 0) return ST_OK;
   if (a.fmt != ST_GEMM_F16X3 || a.d_ff % 256 != 0 || !a.w2 || !a.b2) {
     st_set_error("rp_layer_tail16: needs the f16x3 format, d_ff %% 256 == 0 and w2/b2 (fmt=%d d_ff=%d)", a.fmt, a.d_ff);
@@ -3046,7 +3102,7 @@ static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
   }
   int grid = (n_bound + 63) / 64;
   if (rp_tail_persistent) grid = std::min(grid, st_cu_count());
-  hipLaunchKernelGGL(rp_layer_tail16_kernel<SITE>, dim3(grid), dim3(512), RP_TAIL_LDS, st, a);
+  hipLaunchKernelGGL((rp_layer_tail16_kernel<SITE, EMB>), dim3(grid), dim3(512), LDS, st, a);
   ST_LAUNCH_CHECK();
   return ST_OK;
 }
@@ -3058,6 +3114,13 @@ static int launch_layer_tail16(const OFArgs& a, int n_bound, hipStream_t st) {
 template <int SITE = 0>
 static int launch_layer_tail(const OFArgs& a, int n_bound, hipStream_t st) {
   rp_ab_env();
+  if (a.emb) {
+    if (!rp_tail_shape16) {
+      st_set_error("rp_layer_tail: the embedding residual needs the 16x16x32 form");
+      return ST_EINVAL;
+    }
+    return a.tokens ? launch_layer_tail16<SITE, 2>(a, n_bound, st) : launch_layer_tail16<SITE, 1>(a, n_bound, st);
+  }
   return rp_tail_shape16 ? launch_layer_tail16<SITE>(a, n_bound, st) : launch_layer_tail64(a, n_bound, st);
 }
 
