@@ -580,7 +580,8 @@ __device__ __forceinline__ void tile_linear16(float* Xs, const float* __restrict
 // hide each other's layer-start and score-phase latencies: 1472 -> 1198 us per launch at 98 304 sentences, same box
 // (tools/bench_scorer_step.py).  A 64-row tile (SC16_ROWS 64: one workgroup per CU, half the weight stream out of L2, 224 -
 // 255 registers) measured the same 1.21 ms, and streaming the unit vectors through register buffers one row ahead bought it
-// nothing more: the two-workgroup form is the simplest of the three.  tests/test_gpu_kernels.py::
+// nothing more; 64 rows on 16 waves (the registers of 32 x 8) measured 1.40 ms: the two-workgroup form is the simplest and
+// the fastest of the four.  tests/test_gpu_kernels.py::
 // test_scorer_edit_step_is_bit_reproducible guards the result.
 #ifndef SC16_WAVES_PER_EU
 #define SC16_WAVES_PER_EU (SC16_ROWS > 32 ? 2 : 4)
