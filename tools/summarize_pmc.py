@@ -1,7 +1,7 @@
 """Aggregate a rocprofv3 counter_collection.csv per kernel (sum of each counter over all dispatches), then per PHASE of
 the attack step:
 
-  set-up     encoder kernels (enc_*, rp_layer_tail16_kernel<1>, rp_lin16_kernel<0> / rp_gemm of the encoder's FFN) and the
+  set-up     encoder kernels (enc_*, rp_layer_tail16_kernel<1, ..>, rp_lin16_kernel<0> / rp_gemm of the encoder's FFN) and the
              like / unlike scorer embedding (scorer_kernel<false>)
   edit loop  the scorer edit step (scorer_kernel<true>), every decode kernel (embed, QKV, attention, half-layer kernel <0>,
              generator screening / argmax / finish, cross-attention constants), accept_kernel and the torch glue between them
@@ -16,7 +16,7 @@ import csv
 import re
 import sys
 
-SETUP = re.compile(r"^(void )?(enc_|rp_layer_tail16_kernel<1>|scorer_kernel<false>|rp_lin16_kernel<0>|rp_lin_kernel<0|enc_window)")
+SETUP = re.compile(r"^(void )?(enc_|rp_layer_tail16_kernel<1[,>]|scorer(16)?_kernel<false>|rp_lin16_kernel<0>|rp_lin_kernel<0|enc_window)")
 
 
 def phase(kernel):
