@@ -60,7 +60,7 @@ class AttackConfig:
     # decode steps beats not decoding iterations that may be discarded: up to this many sentences ALL iterations are
     # decoded in one round (batch 256: 12.9 k -> 20.8 k sentences/s with this alone; results identical by construction)
     single_round_max_batch: int = 8192
-    merge_log_decodes_max_jobs: int = 600000   # decode jobs (241 KB of K/V cache each) up to which the log decodes join round 1
+    merge_log_decodes_max_bytes: float = 150e9   # decode workspace up to which the log decodes join round 1 (121 / 241 KB per job)
     defer_stragglers: bool = True  # see run_prepared: sentences whose decodes do not end are finished in an extra round
     count_units: bool = False
 
@@ -297,7 +297,8 @@ class AttackRunner:
         # They ride along in the FIRST decode round of the edit loop (one call of (rounds + 1 + K+ + K-) B jobs instead of
         # two calls with a straggler tail each) unless that would not fit the K/V cache budget.
         n_first = (sched_first(c, I, B) + 1 + kp + kn) * B
-        merge_log = c.log_decodes and (kp or kn) and not (c.retext or c.want_trace) and n_first <= c.merge_log_decodes_max_jobs
+        merge_log = (c.log_decodes and (kp or kn) and not (c.retext or c.want_trace)
+                     and ops.decode_workspace_bytes(self.ae, n_first, c.max_sequence_length) <= c.merge_log_decodes_max_bytes)
         if c.log_decodes and (kp or kn) and not merge_log:
             ref_ids, _, _ = self.decode(lat_all[B:])
             like_ids_dev = ref_ids[:B * kp].view(B, kp, T) if kp else None

@@ -45,6 +45,12 @@ class DecodeWorkspace:
         return self.buf
 
 
+def decode_workspace_bytes(ae, B, max_len=60, l0_table=True):
+    """device workspace st_decode_greedy needs for B decode jobs (K/V cache: 121 KB per job when the first layer reads
+    the (token, position) table, 241 KB otherwise)"""
+    return int(lib().st_decode_workspace_bytes_opt(C.byref(ae.dec), int(B), max_len, 0 if l0_table else _lib.ST_DEC_NO_L0_TABLE))
+
+
 def greedy_decode(ae, latent, max_len=60, start_id=2, eos=3, pad=0, early_exit=True, sync_every=1,
                   want_gap=False, ws: DecodeWorkspace = None, screen=True, l0_table=True):
     """-> (ids [B,max_len-1] int32, gap or None, steps_run).
