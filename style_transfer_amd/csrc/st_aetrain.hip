@@ -19,7 +19,7 @@
 #include <math.h>
 
 #include <algorithm>
-#include "st_common.h"
+#include "st_rowpanel.h"
 
 #ifndef ST_TRY
 #define ST_TRY(x)            \
@@ -599,6 +599,8 @@ struct Ws {
   size_t sl_scratch_bytes;
   float* slab;          // split-K partial products of the weight-gradient GEMMs
   size_t slab_floats;
+  float* wpack;         // fragment-packed image of the weight matrix of the product in flight (row-panel kernels)
+  size_t wpack_floats;
   size_t total;
 };
 
@@ -630,6 +632,8 @@ Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
   w.con_rows = a.f((size_t)(Se / (B > 0 ? B : 1)) * B);
   w.slab_floats = (size_t)AE_MAX_SLICES * 256 * (dff > 768 ? dff : 768);
   w.slab = a.f(w.slab_floats);
+  w.wpack_floats = std::max(rp_packed_floats(V, 256), std::max(rp_packed_floats(256, dff), rp_packed_floats(dff, 256)));
+  w.wpack = a.f(w.wpack_floats);
   w.sl_scratch_bytes = st_simloss_scratch_bytes(B, B);
   w.sl_scratch = base ? base + a.off : nullptr;
   a.off += up256(w.sl_scratch_bytes);
@@ -637,11 +641,55 @@ Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
   return w;
 }
 
+// f32 fragment image (st_rowpanel.h) of W'[n][k] = src[n * sn + k * sk]: W itself (sn = K, sk = 1) or its transpose
+__global__ __launch_bounds__(256) void ae_pack_kernel(const float* __restrict__ src, long sn, long sk, int N, int K,
+                                                      float* __restrict__ out) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the packed image
+  const int kgs = K >> 3;
+  const size_t total = (size_t)((N + 31) / 32) * kgs * 64;
+  if (o >= total) return;
+  const int lane = (int)(o & 63);
+  const int kg = (int)((o >> 6) % kgs);
+  const int blk = (int)((o >> 6) / kgs);
+  const int row = blk * 32 + (lane & 31);
+  f32x4 v = {0, 0, 0, 0};
+  if (row < N) {
+    const float* q = src + (long)row * sn + (long)(kg * 8 + 4 * (lane >> 5)) * sk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = q[(long)j * sk];
+  }
+  *(f32x4*)(out + o * 4) = v;
+}
+
 struct Ctx {
   hipStream_t st;
   int rc;
   float* slab;
   size_t slab_floats;
+  float* wpack;
+  size_t wpack_floats;
+  // Y[rows, N] (+)= X[rows, K] . W'^T + bias with W'[n][k] = Wsrc[n * sn + k * sk], on the exact-f32 ROW-PANEL kernels
+  // (st_rowpanel.h: 64-row panel of X in LDS, fragment-packed W straight from L2; 110 - 130 TFLOP/s where the strided
+  // kernel below reaches 45).  The weights change every step, so the image is packed in front of every product (a few
+  // microseconds); contraction 256, or a multiple of 256 with a 256-wide result.
+  bool rp_ok(int rows, int N, int K) const {
+    static const bool off = getenv("ST_AE_NO_RP") != nullptr;
+    return !off && wpack && rows >= 256 && ((K == 256) || (K % 256 == 0 && N == 256)) && rp_packed_floats(N, K) <= wpack_floats;
+  }
+  int rp_lin(const float* X, const float* Wsrc, long sn, long sk, const float* bias, float* Y, int rows, int N, int K, int acc) {
+    const size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
+    hipLaunchKernelGGL(ae_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Wsrc, sn, sk, N, K, wpack);
+    ST_LAUNCH_CHECK();
+    GemmArgs g = {};
+    g.fmt = ST_GEMM_F32; g.X = X; g.n_host = rows; g.W = wpack; g.bias = bias; g.N = N; g.out = Y; g.ldo = N;
+    if (acc) g.resid = Y;
+    if (K == 256) {
+      const int splits = rp_splits(rows, N, 8, 8);
+      return acc ? launch_rp<EPI_RESID, 8>(g, rows, splits, st) : launch_rp<EPI_BIAS, 8>(g, rows, splits, st);
+    }
+    g.K = K;
+    return acc ? launch_rp_kchunk<EPI_RESID>(g, rows, st, 1) : launch_rp_kchunk<EPI_BIAS>(g, rows, st, 1);
+  }
   int gemm(const float* A, long sai, long sar, const float* Bm, long sbr, long sbj, float* C, int ldc, const float* bias, int M, int N,
            int R, int accumulate) {
     if (M <= 0 || N <= 0) return ST_OK;
@@ -671,11 +719,17 @@ struct Ctx {
   }
   // Y[rows,N] = X[rows,K] W^T + b      (W row-major [N,K])
   int lin(const float* X, const float* W, const float* b, float* Y, int rows, int N, int K) {
+    if (rp_ok(rows, N, K)) return rp_lin(X, W, K, 1, b, Y, rows, N, K, 0);
     return gemm(X, K, 1, W, 1, K, Y, N, b, rows, N, K, 0);
   }
   // dX (+)= dY W;  dW = dY^T X;  db = column sums of dY
   int lin_bwd(const float* dY, const float* X, const float* W, float* dX, int acc_dx, float* dW, float* db, int rows, int N, int K) {
-    if (dX) ST_TRY(gemm(dY, N, 1, W, K, 1, dX, K, nullptr, rows, K, N, acc_dx));
+    if (dX) {
+      if (rp_ok(rows, K, N))   // dX[rows, K] = dY[rows, N] . W[N, K]: the "weight" of this product is W^T
+        ST_TRY(rp_lin(dY, W, 1, K, nullptr, dX, rows, K, N, acc_dx));
+      else
+        ST_TRY(gemm(dY, N, 1, W, K, 1, dX, K, nullptr, rows, K, N, acc_dx));
+    }
     if (dW) ST_TRY(gemm(dY, 1, N, X, K, 1, dW, K, nullptr, N, K, rows, 0));
     if (db) ST_TRY(colsum(dY, rows, N, db));
     return ST_OK;
@@ -714,7 +768,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     st_set_error("st_ae_train_step: workspace too small: need %zu bytes, have %zu", w.total, workspace_bytes);
     return ST_ENOMEM;
   }
-  Ctx c{(hipStream_t)stream, 0, w.slab, w.slab_floats};
+  Ctx c{(hipStream_t)stream, 0, w.slab, w.slab_floats, w.wpack, w.wpack_floats};
   const int Re = n_enc_rows, Se = n_enc_sent, Rd = n_dec_rows, L = p->n_layers, dff = p->d_ff, V = p->vocab;
   const int n_views = Se / B - 1;
   auto drop = [&](uint32_t site) { return Drop{seed, drop_p, drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f, site}; };
