@@ -519,8 +519,15 @@ def main(argv=None):
             bfile = os.path.join(ROOT, "profiles", "r03_pmc_phase_mfma_busy.json")
             busy = None
             if split and gen_n.value > 0:
-                # per row: attention output + residual + cross-attention constant read, layer output written (f32 x 256)
-                alg_bytes = gen_fl.value / gen_n.value / (2.0 * 256 * (256 + 2 * 1024)) * 4 * 1024
+                # HBM bytes the kernel has to move, per row and layer (f32 x 256 = 1 KB each): attention output read, layer
+                # output written, residual read (not in the first layer when it reads the tables: the kernel computes the
+                # embedding row from the L2-resident table), cross-attention constant read (decoder only).  Rows: executed
+                # token-steps x decoder layers + encoder token rows x encoder layers (the few steps below 64 live rows run
+                # other kernels).
+                tabs = ae.dec.l0_table_len > 0
+                kb_dec = (3 if tabs else 4) + 4 * (ae.dec.n_layers - 1)
+                kb_enc = (2 if tabs else 3) + 3 * (ae.enc.n_layers - 1)
+                alg_bytes = (tot[0] * kb_dec + tot[4] * kb_enc) * 1024.0 / world / gen_n.value
                 default_cfg = (a.shape == "yelp" and a.tokens == "zipf" and B == 98304 and not a.fixed_steps
                                and a.iters_per_decode == "12,6" and not a.log_decodes)
                 if default_cfg and os.path.exists(tfile):
@@ -575,6 +582,12 @@ def main(argv=None):
                              "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
                              "traffic_source": traffic_src,
                              "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_note": ("algorithmic = attention output + residual + cross-attention constant read, output written, per "
+                                          "row and layer; the first-layer launches compute their residual from the 9.5 MB embedding "
+                                          "table, which is counted as cache-resident here but mostly misses the 4 MB of L2 per XCD "
+                                          "(the measured traffic did not change when those launches stopped reading x): that and "
+                                          "weight fragments that miss L2 are the excess; at 8 TB/s the traffic is 0.19 ms of a 1.04 ms "
+                                          "launch") if split else None,
                              "mfma_flops_per_algorithmic_flop": 3 if split else 1,
                              "mfma_issue_frac": achieved * (3 if split else 1) / peak,
                              "achieved_over_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
