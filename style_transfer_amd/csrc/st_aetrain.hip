@@ -156,6 +156,164 @@ __global__ __launch_bounds__(256) void ae_slab_sum_kernel(GArgs a, const float* 
   *c = (a.accumulate ? *c : 0.0f) + s + (a.bias ? a.bias[j] : 0.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradients: C[i][j] = sum_r A[r][i] B[r][j] (A = dY [R, M], B = X [R, N], both row-major) and, from the same
+// loads, db[i] = sum_r A[r][i].  Both operands are contiguous along the NON-contracted index, which is exactly how
+// v_mfma_f32_32x32x2_f32 wants them (lane = output index, lane half = contraction index): every operand register is one
+// coalesced dword load (two rows of 32 consecutive floats per wave), no LDS, no barrier.  A wave owns a 64 x 64 tile
+// (4 accumulators), a workgroup 128 x 128 (the two waves sharing an operand meet in the vector L1); operands of the next
+// 16 rows are in flight under the 32 MFMAs of the current 16.  The contraction is cut into nz slices of whole 16-row
+// batches, one workgroup per (tile, slice), the tiles of a slice on ONE XCD (they read the same rows: its L2 serves the
+// second reader); partial products go to slab[z][i][j] and ae_dw_sum_kernel adds them in slice order (fixed order:
+// results do not depend on scheduling).  Out-of-range output columns read a clamped address: their garbage only
+// reaches accumulators that are never stored.  (The strided LDS kernel above ran these products at ~ 32 TFLOP/s:
+// transposed operand staging with 8-way bank conflicts, two barriers per 32 rows.)
+// ------------------------------------------------------------------------------------------------
+struct DwArgs {
+  const float* A;
+  const float* B;
+  float* slab;    // [nz][M][N]
+  float* dbslab;  // [nz][M] or null
+  int M, N, R, lda, ldb;
+  int nz, per, tiles_n, tiles;
+};
+#ifndef DW_U
+#define DW_U 8  /* contraction pairs per batch: 16 rows */
+#endif
+#ifdef DW_WITH_FENCE
+#define DW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DW_FENCE()  /* measured: pinning the whole batch of loads in front of the MFMAs is slower (303 against 213 us per launch) */
+#endif
+// VEC 2 (M, N even): lane l of a half holds outputs 2 l and 2 l + 1 of its 64 and loads them as one dwordx2 (half the
+// load instructions: 190 against 209 us per launch); VEC 1: outputs l and l + 32, any M, N (the generator's odd vocabulary)
+template <int VEC>
+__global__ __launch_bounds__(256) void ae_dw_kernel(DwArgs a) {
+  const int nb = gridDim.x;  // a multiple of 8
+  const int vid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  if (vid >= a.tiles * a.nz) return;
+  const int tile = vid % a.tiles, z = vid / a.tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int i0 = (tile / a.tiles_n) * 128 + (wave >> 1) * 64, j0 = (tile % a.tiles_n) * 128 + (wave & 1) * 64;
+  const int r_lo = z * a.per, r_hi = min(a.R, r_lo + a.per);
+  const bool want_db = a.dbslab && (tile % a.tiles_n) == 0 && (wave & 1) == 0;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][p][r] = 0.0f;
+  float sa0 = 0.0f, sa1 = 0.0f;
+  const long sa = 2L * a.lda, sb = 2L * a.ldb;
+  const int ca = VEC == 2 ? 2 * l31 : l31, cs = VEC == 2 ? 1 : 32;  // the lane's two outputs of the wave's 64: ca, ca + cs
+  const float* pa0 = a.A + (long)(r_lo + half) * a.lda + min(i0 + ca, a.M - 1 - (VEC == 2));
+  const float* pb0 = a.B + (long)(r_lo + half) * a.ldb + min(j0 + ca, a.N - 1 - (VEC == 2));
+  const float* pa1 = VEC == 2 ? pa0 + 1 : a.A + (long)(r_lo + half) * a.lda + min(i0 + 32 + l31, a.M - 1);
+  const float* pb1 = VEC == 2 ? pb0 + 1 : a.B + (long)(r_lo + half) * a.ldb + min(j0 + 32 + l31, a.N - 1);
+  float ca0[DW_U], ca1[DW_U], cb0[DW_U], cb1[DW_U], na0[DW_U], na1[DW_U], nb0[DW_U], nb1[DW_U];
+  const int n_full = r_hi > r_lo ? (r_hi - r_lo) / (2 * DW_U) : 0;
+  auto fetch = [&](float (&x0)[DW_U], float (&x1)[DW_U], float (&y0)[DW_U], float (&y1)[DW_U]) {
+#pragma unroll
+    for (int u = 0; u < DW_U; ++u) {
+      if constexpr (VEC == 2) {
+        const float2 xa = *(const float2*)(pa0 + u * sa), xb = *(const float2*)(pb0 + u * sb);
+        x0[u] = xa.x; x1[u] = xa.y; y0[u] = xb.x; y1[u] = xb.y;
+      } else {
+        x0[u] = pa0[u * sa];
+        x1[u] = pa1[u * sa];
+        y0[u] = pb0[u * sb];
+        y1[u] = pb1[u * sb];
+      }
+    }
+    pa0 += DW_U * sa; pa1 += DW_U * sa; pb0 += DW_U * sb; pb1 += DW_U * sb;
+  };
+  auto mac = [&](const float (&x0)[DW_U], const float (&x1)[DW_U], const float (&y0)[DW_U], const float (&y1)[DW_U]) {
+#pragma unroll
+    for (int u = 0; u < DW_U; ++u) {
+      acc[0][0] = mfma32(x0[u], y0[u], acc[0][0]);
+      acc[0][1] = mfma32(x0[u], y1[u], acc[0][1]);
+      acc[1][0] = mfma32(x1[u], y0[u], acc[1][0]);
+      acc[1][1] = mfma32(x1[u], y1[u], acc[1][1]);
+    }
+    if (want_db) {
+#pragma unroll
+      for (int u = 0; u < DW_U; ++u) {
+        sa0 += x0[u];
+        sa1 += x1[u];
+      }
+    }
+  };
+  // two register sets in turn, no conditional inside the loop: the wait in front of a batch's MFMAs then counts exactly
+  // the 32 younger loads (a copy "current = next" makes the compiler wait for the loads it has just issued)
+  int b = 0;
+  if (n_full > 0) {
+    fetch(ca0, ca1, cb0, cb1);
+    for (; b + 2 < n_full; b += 2) {
+      fetch(na0, na1, nb0, nb1);
+      DW_FENCE();
+      mac(ca0, ca1, cb0, cb1);
+      DW_FENCE();
+      fetch(ca0, ca1, cb0, cb1);
+      DW_FENCE();
+      mac(na0, na1, nb0, nb1);
+      DW_FENCE();
+    }
+    mac(ca0, ca1, cb0, cb1);
+    ++b;
+  }
+  // what is left (at most one whole batch and a partial one), one batch at a time; rows past the end contribute zeros
+  for (int r0 = r_lo + b * 2 * DW_U; r0 < r_hi; r0 += 2 * DW_U) {
+#pragma unroll
+    for (int u = 0; u < DW_U; ++u) {
+      const int r = r0 + 2 * u + half;
+      const bool ok = r < r_hi;
+      const long ra = (long)(ok ? r : r_hi - 1) - (r0 + half);  // row offset from the pointers' row
+      const float x0 = pa0[ra * a.lda], x1 = pa1[ra * a.lda], y0 = pb0[ra * a.ldb], y1 = pb1[ra * a.ldb];
+      ca0[u] = ok ? x0 : 0.0f; ca1[u] = ok ? x1 : 0.0f; cb0[u] = ok ? y0 : 0.0f; cb1[u] = ok ? y1 : 0.0f;
+    }
+    pa0 += DW_U * sa; pa1 += DW_U * sa; pb0 += DW_U * sb; pb1 += DW_U * sb;
+    mac(ca0, ca1, cb0, cb1);
+  }
+  float* out = a.slab + (size_t)z * a.M * a.N;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int j = j0 + ca + cs * p;
+      if (j >= a.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + (VEC == 2 ? 2 * mfma32_row(r, lane) + q : 32 * q + mfma32_row(r, lane));
+        if (i < a.M) out[(size_t)i * a.N + j] = acc[q][p][r];
+      }
+    }
+  if (want_db) {  // lane half h holds the rows of parity h: even rows + odd rows
+    sa0 += __shfl_down(sa0, 32);
+    sa1 += __shfl_down(sa1, 32);
+    if (half == 0) {
+      if (i0 + ca < a.M) a.dbslab[(size_t)z * a.M + i0 + ca] = sa0;
+      if (i0 + ca + cs < a.M) a.dbslab[(size_t)z * a.M + i0 + ca + cs] = sa1;
+    }
+  }
+}
+// C[i][j] = sum_z slab[z][i][j]; db[i] = sum_z dbslab[z][i]; slices added in index order
+__global__ __launch_bounds__(256) void ae_dw_sum_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab, int nz, int M,
+                                                        int N, float* __restrict__ C, int ldc, float* __restrict__ db) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, mn = (size_t)M * N;
+  if (e < mn) {
+    float s = 0.0f;
+#pragma unroll 8
+    for (int z = 0; z < nz; ++z) s += slab[(size_t)z * mn + e];
+    C[(e / N) * ldc + (e % N)] = s;
+  } else if (e < mn + M && db) {
+    const int i = (int)(e - mn);
+    float s = 0.0f;
+    for (int z = 0; z < nz; ++z) s += dbslab[(size_t)z * M + i];
+    db[i] = s;
+  }
+}
+
 // column sums: out[c] = sum_rows X[row][c], in two fixed-order stages: grid (64-column blocks, row slices) -> part[slice][c],
 // then one thread per column adds the slices.  (One workgroup per 64 columns walking all rows was 45 % of the step.)
 #define AE_COLSUM_SLICES 64
@@ -228,10 +386,12 @@ __global__ __launch_bounds__(256) void ae_ln_fwd_kernel(const float* __restrict_
   const f32x4 ga = *(const f32x4*)(a + lane * 4), gb = *(const f32x4*)(b + lane * 4);
   *(f32x4*)(y + (size_t)r * 256 + lane * 4) = ga * (c * inv) + gb;
 }
-// dx (+)= LN'(dy); da += sum dy * xhat, db += sum dy  (f32 atomics into [256])
+// dx (+)= LN'(dy); part[block] = (sum dy * xhat, sum dy) over the block's rows [2][256]; ae_ln_bwd_finish_kernel adds the
+// blocks in index order (the first form ran on 64 workgroups with float atomics into da / db: a quarter of the chip,
+// and sums whose last bits depended on the order the workgroups finished in)
 __global__ __launch_bounds__(256) void ae_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ a, int n, float* __restrict__ dx,
-                                                        int accumulate, float* __restrict__ da, float* __restrict__ db) {
+                                                        int accumulate, float* __restrict__ part) {
   __shared__ float sa[4][256], sb[4][256];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   f32x4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
@@ -263,8 +423,17 @@ __global__ __launch_bounds__(256) void ae_ln_bwd_kernel(const float* __restrict_
   }
   __syncthreads();
   const int c = threadIdx.x;
-  atomicAdd(da + c, (sa[0][c] + sa[1][c]) + (sa[2][c] + sa[3][c]));
-  atomicAdd(db + c, (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]));
+  part[(size_t)blockIdx.x * 512 + c] = (sa[0][c] + sa[1][c]) + (sa[2][c] + sa[3][c]);
+  part[(size_t)blockIdx.x * 512 + 256 + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
+}
+__global__ __launch_bounds__(512) void ae_ln_bwd_finish_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ da,
+                                                               float* __restrict__ db) {
+  const int c = threadIdx.x;  // 0 .. 255: da, 256 .. 511: db
+  float s = 0.0f;
+#pragma unroll 8
+  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 512 + c];
+  float* o = c < 256 ? da + c : db + (c - 256);
+  *o += s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,12 +511,14 @@ __global__ __launch_bounds__(256) void ae_latent_bwd_kernel(const float* __restr
 #define ATT_TILE (64 * 65)
 __global__ __launch_bounds__(64) void ae_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, const int32_t* __restrict__ off,
-                                                         int causal, Drop dr, float* __restrict__ P, float* __restrict__ out) {
+                                                         int causal, Drop dr, float* __restrict__ P, float* __restrict__ out,
+                                                         int short_elsewhere) {
   extern __shared__ float sm[];
   float* Ks = sm;             // [64][65]
   float* Vs = sm + ATT_TILE;
   const int s = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
   const int r0 = off[s], L = off[s + 1] - r0;
+  if (L <= short_elsewhere) return;
   for (int e = i; e < L * 64; e += 64) {
     const int j = e >> 6, d = e & 63;
     Ks[j * 65 + d] = k[(size_t)(r0 + j) * 256 + h * 64 + d];
@@ -396,7 +567,7 @@ __global__ __launch_bounds__(64) void ae_attn_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ v, const float* __restrict__ P,
                                                          const float* __restrict__ dout, const int32_t* __restrict__ off,
                                                          int causal, Drop dr, float* __restrict__ dq, float* __restrict__ dk,
-                                                         float* __restrict__ dv) {
+                                                         float* __restrict__ dv, int short_elsewhere) {
   extern __shared__ float sm[];
   float* Ks = sm;                 // [64][65]
   float* Vs = sm + ATT_TILE;
@@ -406,6 +577,7 @@ __global__ __launch_bounds__(64) void ae_attn_bwd_kernel(const float* __restrict
   float* Ds = sm + 5 * ATT_TILE;  // dropped P [query][key]
   const int s = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
   const int r0 = off[s], L = off[s + 1] - r0;
+  if (L <= short_elsewhere) return;
   for (int e = i; e < L * 64; e += 64) {
     const int j = e >> 6, d = e & 63;
     const size_t g = (size_t)(r0 + j) * 256 + h * 64 + d;
@@ -460,6 +632,221 @@ __global__ __launch_bounds__(64) void ae_attn_bwd_kernel(const float* __restrict
     for (int d = 0; d < 64; ++d) {
       dk[(size_t)(r0 + i) * 256 + h * 64 + d] = dkj[d];
       dv[(size_t)(r0 + i) * 256 + h * 64 + d] = dvj[d];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same two passes for sentences of at most 16 positions (all of yelp; the kernels above keep the longer ones and
+// leave these alone, and the other way round: both are launched, each workgroup looks at its sentence's length first).
+// One workgroup per sentence, one wave per head; lane = (row i = lane & 15, quarter c = lane >> 4 of the head's 64
+// features), so a 9-token sentence keeps 36 lanes of every wave busy where the lane-per-row kernels keep 9, and a tile
+// is 4 KB of LDS instead of 16.6 (two workgroups per CU instead of one WAVE per CU in the backward pass).  Dot products
+// over the 64 features: 16 terms in the lane, then the four quarters by two xor-shuffles ((c0 + c1) + (c2 + c3), the same
+// value in all four lanes).  P keeps its [row][head][64] layout; only its first 16 entries are written and read here.
+// ------------------------------------------------------------------------------------------------
+#define ATT16_TILE (16 * 64)
+// the key loops are unrolled 16 times (their per-key results live in registers); without a fence every four keys the
+// compiler hoists all 64 LDS reads of a loop to its top and spills
+#define ATT16_FENCE(j) do { if (((j) & 3) == 3) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+__device__ __forceinline__ float quarter_sum(float p) {
+  p += __shfl_xor(p, 16);
+  p += __shfl_xor(p, 32);
+  return p;
+}
+// dropout factors of one query row's 16 keys: quarter c hashes keys 4c .. 4c + 3, the row's four lanes exchange them
+// (the counter hash is ~ 60 integer instructions per element; no LDS read shares a basic block with its branch)
+__device__ __forceinline__ void att16_drop_factors(const Drop& dr, uint64_t base, int nk, int i, int c, float (&f)[16]) {
+  float own[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) own[t] = 4 * c + t < nk ? drop_factor(dr, base + 4 * c + t) : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) f[j] = __shfl(own[j & 3], i + 16 * (j >> 2));
+}
+// rows j = (lane >> 4) + 4 t of a [16][64] tile from the head's 64 columns of a [rows][256] matrix
+__device__ __forceinline__ void att16_stage(float* __restrict__ tile, const float* __restrict__ src, int r0, int L, int h, int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = (lane >> 4) + 4 * t;
+    f32x4 v = {0, 0, 0, 0};
+    if (j < L) v = *(const f32x4*)(src + (size_t)(r0 + j) * 256 + h * 64 + 4 * (lane & 15));
+    *(f32x4*)(tile + j * 64 + 4 * (lane & 15)) = v;
+  }
+}
+__global__ __launch_bounds__(256, 4) void ae_attn16_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const int32_t* __restrict__ off,
+                                                            int causal, Drop dr, float* __restrict__ P, float* __restrict__ out) {
+  __shared__ __align__(16) float sm[4][2 * ATT16_TILE + 256];
+  const int s = blockIdx.x, h = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, c = lane >> 4;
+  const int r0 = off[s], L = off[s + 1] - r0;
+  if (L > 16) return;
+  float* Ks = sm[h];
+  float* Vs = sm[h] + ATT16_TILE;
+  float* Pd = Vs + ATT16_TILE;  // dropped P [query][key]
+  att16_stage(Ks, k, r0, L, h, lane);
+  att16_stage(Vs, v, r0, L, h, lane);
+  __syncthreads();
+  if (i >= L) return;
+  f32x4 qi[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) qi[t] = *(const f32x4*)(q + (size_t)(r0 + i) * 256 + h * 64 + 16 * c + 4 * t);
+  const int nk = causal ? i + 1 : L;
+  float sc[16];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float p = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 kk = *(const f32x4*)(Ks + j * 64 + 16 * c + 4 * t);
+      p = fmaf(qi[t].x, kk.x, p); p = fmaf(qi[t].y, kk.y, p); p = fmaf(qi[t].z, kk.z, p); p = fmaf(qi[t].w, kk.w, p);
+    }
+    sc[j] = quarter_sum(p) * 0.125f;
+    if (j < nk) m = fmaxf(m, sc[j]);
+    ATT16_FENCE(j);
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sc[j] = j < nk ? expf(sc[j] - m) : 0.0f;
+    sum += sc[j];
+  }
+  const float inv = 1.0f / sum;
+  const uint64_t base = (((uint64_t)s * 4 + h) * 64 + i) * 64;
+  float f[16];
+  att16_drop_factors(dr, base, nk, i, c, f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sc[j] *= inv;
+  // quarter c keeps entries 4c .. 4c + 3 of the row: P to global memory, the dropped P to LDS for the rolled loop below
+  // (an unrolled P.V loop gets its 64 LDS reads hoisted in front of its 256 FMAs, and spills)
+  const f32x4 pw = {c == 0 ? sc[0] : c == 1 ? sc[4] : c == 2 ? sc[8] : sc[12], c == 0 ? sc[1] : c == 1 ? sc[5] : c == 2 ? sc[9] : sc[13],
+                    c == 0 ? sc[2] : c == 1 ? sc[6] : c == 2 ? sc[10] : sc[14], c == 0 ? sc[3] : c == 1 ? sc[7] : c == 2 ? sc[11] : sc[15]};
+  const f32x4 fw = {c == 0 ? f[0] : c == 1 ? f[4] : c == 2 ? f[8] : f[12], c == 0 ? f[1] : c == 1 ? f[5] : c == 2 ? f[9] : f[13],
+                    c == 0 ? f[2] : c == 1 ? f[6] : c == 2 ? f[10] : f[14], c == 0 ? f[3] : c == 1 ? f[7] : c == 2 ? f[11] : f[15]};
+  *(f32x4*)(P + ((size_t)(r0 + i) * 4 + h) * 64 + 4 * c) = pw;
+  *(f32x4*)(Pd + i * 16 + 4 * c) = pw * fw;
+  __syncthreads();
+  f32x4 o[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll 2
+  for (int j = 0; j < nk; ++j) {
+    const float pd = Pd[i * 16 + j];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 vv = *(const f32x4*)(Vs + j * 64 + 16 * c + 4 * t);
+      o[t].x = fmaf(pd, vv.x, o[t].x); o[t].y = fmaf(pd, vv.y, o[t].y); o[t].z = fmaf(pd, vv.z, o[t].z); o[t].w = fmaf(pd, vv.w, o[t].w);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) *(f32x4*)(out + (size_t)(r0 + i) * 256 + h * 64 + 16 * c + 4 * t) = o[t];
+}
+
+__global__ __launch_bounds__(256, 4) void ae_attn16_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ P,
+                                                               const float* __restrict__ dout, const int32_t* __restrict__ off,
+                                                               int causal, Drop dr, float* __restrict__ dq, float* __restrict__ dk,
+                                                               float* __restrict__ dv) {
+  __shared__ __align__(16) float sm[4][2 * ATT16_TILE + 2 * 256];
+  const int s = blockIdx.x, h = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, c = lane >> 4;
+  const int r0 = off[s], L = off[s + 1] - r0;
+  if (L > 16) return;
+  // two tiles: K and V for the first phase (lane = query row), then Q and d out for the second (lane = key row); the
+  // second pair waits in registers from the start
+  float* Ks = sm[h];
+  float* Vs = Ks + ATT16_TILE;
+  float* Qs = Ks;
+  float* Gs = Vs;
+  float* Ss = Vs + ATT16_TILE;  // dS [query][key]
+  float* Ds = Ss + 256;         // dropped P [query][key]
+  f32x4 rq[4], rg[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = (lane >> 4) + 4 * t;
+    rq[t] = rg[t] = f32x4{0, 0, 0, 0};
+    if (j < L) {
+      rq[t] = *(const f32x4*)(q + (size_t)(r0 + j) * 256 + h * 64 + 4 * (lane & 15));
+      rg[t] = *(const f32x4*)(dout + (size_t)(r0 + j) * 256 + h * 64 + 4 * (lane & 15));
+    }
+  }
+  att16_stage(Ks, k, r0, L, h, lane);
+  att16_stage(Vs, v, r0, L, h, lane);
+  __syncthreads();
+  {  // lane = (query row i, quarter c)
+    const bool live = i < L;
+    const int nk = live ? (causal ? i + 1 : L) : 0;
+    const uint64_t base = (((uint64_t)s * 4 + h) * 64 + i) * 64;
+    f32x4 gi[4], pr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      gi[t] = live ? *(const f32x4*)(dout + (size_t)(r0 + i) * 256 + h * 64 + 16 * c + 4 * t) : f32x4{0, 0, 0, 0};
+      pr[t] = live ? *(const f32x4*)(P + ((size_t)(r0 + i) * 4 + h) * 64 + 4 * t) : f32x4{0, 0, 0, 0};
+    }
+    float dp[16], dd[16];
+    att16_drop_factors(dr, base, nk, i, c, dd);
+    float dot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float p = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 vv = *(const f32x4*)(Vs + j * 64 + 16 * c + 4 * t);
+        p = fmaf(gi[t].x, vv.x, p); p = fmaf(gi[t].y, vv.y, p); p = fmaf(gi[t].z, vv.z, p); p = fmaf(gi[t].w, vv.w, p);
+      }
+      const float dpd = quarter_sum(p);
+      const float pij = pr[j >> 2][j & 3];
+      const float f = dd[j];
+      dp[j] = dpd * f;
+      dd[j] = pij * f;
+      if (j < nk) dot = fmaf(dp[j], pij, dot);
+      ATT16_FENCE(j);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dp[j] = j < nk ? pr[j >> 2][j & 3] * (dp[j] - dot) * 0.125f : 0.0f;  // d score (the 1/sqrt(d_k) folded in)
+    // quarter c stores entries 4c .. 4c + 3 of its row of dS and of the dropped P (all four quarters hold the same values)
+    const f32x4 sw = {c == 0 ? dp[0] : c == 1 ? dp[4] : c == 2 ? dp[8] : dp[12], c == 0 ? dp[1] : c == 1 ? dp[5] : c == 2 ? dp[9] : dp[13],
+                      c == 0 ? dp[2] : c == 1 ? dp[6] : c == 2 ? dp[10] : dp[14], c == 0 ? dp[3] : c == 1 ? dp[7] : c == 2 ? dp[11] : dp[15]};
+    const f32x4 dw = {c == 0 ? dd[0] : c == 1 ? dd[4] : c == 2 ? dd[8] : dd[12], c == 0 ? dd[1] : c == 1 ? dd[5] : c == 2 ? dd[9] : dd[13],
+                      c == 0 ? dd[2] : c == 1 ? dd[6] : c == 2 ? dd[10] : dd[14], c == 0 ? dd[3] : c == 1 ? dd[7] : c == 2 ? dd[11] : dd[15]};
+    *(f32x4*)(Ss + i * 16 + 4 * c) = sw;
+    *(f32x4*)(Ds + i * 16 + 4 * c) = dw;
+    __syncthreads();
+    f32x4 dqi[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll 2
+    for (int j = 0; j < nk; ++j) {  // rolled, dS from LDS: unrolled, its 64 LDS reads are hoisted in front of the FMAs and spill
+      const float ds = Ss[i * 16 + j];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 kk = *(const f32x4*)(Ks + j * 64 + 16 * c + 4 * t);
+        dqi[t].x = fmaf(ds, kk.x, dqi[t].x); dqi[t].y = fmaf(ds, kk.y, dqi[t].y); dqi[t].z = fmaf(ds, kk.z, dqi[t].z); dqi[t].w = fmaf(ds, kk.w, dqi[t].w);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) *(f32x4*)(dq + (size_t)(r0 + i) * 256 + h * 64 + 16 * c + 4 * t) = dqi[t];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = (lane >> 4) + 4 * t;
+    *(f32x4*)(Qs + j * 64 + 4 * (lane & 15)) = rq[t];
+    *(f32x4*)(Gs + j * 64 + 4 * (lane & 15)) = rg[t];
+  }
+  __syncthreads();
+  if (i < L) {  // lane = (key row j = i, quarter c): sums over the query rows in index order
+    f32x4 dkj[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, dvj[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int qi = 0; qi < L; ++qi) {
+      const float ds = Ss[qi * 16 + i], pd = Ds[qi * 16 + i];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 qq = *(const f32x4*)(Qs + qi * 64 + 16 * c + 4 * t), gg = *(const f32x4*)(Gs + qi * 64 + 16 * c + 4 * t);
+        dkj[t].x = fmaf(ds, qq.x, dkj[t].x); dkj[t].y = fmaf(ds, qq.y, dkj[t].y); dkj[t].z = fmaf(ds, qq.z, dkj[t].z); dkj[t].w = fmaf(ds, qq.w, dkj[t].w);
+        dvj[t].x = fmaf(pd, gg.x, dvj[t].x); dvj[t].y = fmaf(pd, gg.y, dvj[t].y); dvj[t].z = fmaf(pd, gg.z, dvj[t].z); dvj[t].w = fmaf(pd, gg.w, dvj[t].w);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      *(f32x4*)(dk + (size_t)(r0 + i) * 256 + h * 64 + 16 * c + 4 * t) = dkj[t];
+      *(f32x4*)(dv + (size_t)(r0 + i) * 256 + h * 64 + 16 * c + 4 * t) = dvj[t];
     }
   }
 }
@@ -587,6 +974,7 @@ struct LayerSave {
   float *x_in, *n0, *q, *k, *v, *P, *att, *x1, *u, *x2, *n2, *h;  // u / x2: decoder only (source-attention sublayer)
 };
 #define AE_MAX_SLICES 16
+#define AE_DW_SLAB_FLOATS (1u << 23)  /* 32 MB: 128 slices of a 256 x 256 gradient, 32 of a 256 x 1024 one */
 struct Ws {
   // encoder (Re rows), decoder (Rd rows)
   int32_t *e_row_sent, *d_row_sent;
@@ -630,7 +1018,8 @@ Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
   w.th = a.f((size_t)R * dff);
   w.sl_loss = a.f(B); w.sl_lse = a.f(B); w.sl_g = a.f(B); w.sl_dori = a.f((size_t)B * 256); w.sl_dlike = a.f((size_t)B * 256);
   w.con_rows = a.f((size_t)(Se / (B > 0 ? B : 1)) * B);
-  w.slab_floats = (size_t)AE_MAX_SLICES * 256 * (dff > 768 ? dff : 768);
+  // split-contraction partial products: the strided kernel's slices, and ae_dw_kernel's [nz][M][N] + [nz][M]
+  w.slab_floats = std::max((size_t)AE_MAX_SLICES * 256 * (dff > 768 ? dff : 768), (size_t)AE_DW_SLAB_FLOATS + 4 * (size_t)V * 256);
   w.slab = a.f(w.slab_floats);
   w.wpack_floats = std::max(rp_packed_floats(V, 256), std::max(rp_packed_floats(256, dff), rp_packed_floats(dff, 256)));
   w.wpack = a.f(w.wpack_floats);
@@ -707,6 +1096,42 @@ struct Ctx {
     ST_LAUNCH_CHECK();
     return ST_OK;
   }
+  // dW[M, N] = dY[R, M]^T X[R, N] and db = column sums of dY, on ae_dw_kernel (slices of the contraction until ~ 3 workgroups per CU)
+  bool dw_ok(int M, int N, int R) const {
+    static const bool off = getenv("ST_AE_NO_DW") != nullptr;
+    return !off && slab && R >= 256 && (size_t)M * N + M <= slab_floats;
+  }
+  int dw(const float* dY, const float* X, float* dW, float* db, int M, int N, int R) {
+    DwArgs a = {};
+    a.A = dY; a.B = X; a.M = M; a.N = N; a.R = R; a.lda = M; a.ldb = N;
+    a.tiles_n = (N + 127) / 128;
+    a.tiles = a.tiles_n * ((M + 127) / 128);
+    int nz = std::max(1, std::min((768 + a.tiles - 1) / a.tiles, R / 64));
+    while (nz > 1 && (size_t)nz * ((size_t)M * N + M) > slab_floats) --nz;
+    a.per = ((R + nz - 1) / nz + 2 * DW_U - 1) / (2 * DW_U) * (2 * DW_U);
+    a.nz = (R + a.per - 1) / a.per;
+    a.slab = slab;
+    a.dbslab = db ? slab + (size_t)a.nz * M * N : nullptr;
+    const int blocks = (a.tiles * a.nz + 7) / 8 * 8;
+    if (((M | N) & 1) == 0 && (((uintptr_t)dY | (uintptr_t)X) & 7) == 0)
+      hipLaunchKernelGGL(ae_dw_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(ae_dw_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+    const size_t e = (size_t)M * N + (db ? M : 0);
+    hipLaunchKernelGGL(ae_dw_sum_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, (const float*)a.slab, (const float*)a.dbslab,
+                       a.nz, M, N, dW, N, db);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
+  // LayerNorm backward over `rows` rows: dx, and da / db += the column sums, through per-block partial sums in the slab
+  int ln_bwd(const float* dy, const float* x, const float* a, int rows, float* dx, int accumulate, float* da, float* db) {
+    int nb = std::max(1, std::min(1024, (rows + 3) / 4));
+    while (nb > 1 && (size_t)nb * 512 > slab_floats) --nb;
+    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, x, a, rows, dx, accumulate, slab);
+    hipLaunchKernelGGL(ae_ln_bwd_finish_kernel, dim3(1), dim3(512), 0, st, (const float*)slab, nb, da, db);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
   int colsum(const float* X, int rows, int N, float* out) {
     int ns = std::min(AE_COLSUM_SLICES, std::max(1, rows / 64));
     while (ns > 1 && (size_t)ns * N > slab_floats) --ns;
@@ -730,6 +1155,7 @@ struct Ctx {
       else
         ST_TRY(gemm(dY, N, 1, W, K, 1, dX, K, nullptr, rows, K, N, acc_dx));
     }
+    if (dW && dw_ok(N, K, rows)) return dw(dY, X, dW, db, N, K, rows);
     if (dW) ST_TRY(gemm(dY, 1, N, X, K, 1, dW, K, nullptr, N, K, rows, 0));
     if (db) ST_TRY(colsum(dY, rows, N, db));
     return ST_OK;
@@ -773,6 +1199,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
   const int n_views = Se / B - 1;
   auto drop = [&](uint32_t site) { return Drop{seed, drop_p, drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f, site}; };
   const size_t att_fwd_lds = 2 * ATT_TILE * 4, att_bwd_lds = 6 * ATT_TILE * 4;
+  static const bool att16 = getenv("ST_AE_NO_ATT16") == nullptr;  // sentences of <= 16 positions on the (row, quarter) kernels
   ST_ENSURE_LDS(ae_attn_bwd_kernel, (int)att_bwd_lds);
 
   ST_HIP(hipMemsetAsync(grads_flat, 0, (size_t)n_params * 4, c.st));
@@ -788,8 +1215,10 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     ST_TRY(c.lin(s.n0, y.wq, y.bq, s.q, rows, 256, 256));
     ST_TRY(c.lin(s.n0, y.wk, y.bk, s.k, rows, 256, 256));
     ST_TRY(c.lin(s.n0, y.wv, y.bv, s.v, rows, 256, 256));
+    if (att16)
+      hipLaunchKernelGGL(ae_attn16_fwd_kernel, dim3(n_sent), dim3(256), 0, c.st, s.q, s.k, s.v, off, dec ? 1 : 0, drop(site0 + 0), s.P, s.att);
     hipLaunchKernelGGL(ae_attn_fwd_kernel, dim3(n_sent, 4), dim3(64), att_fwd_lds, c.st, s.q, s.k, s.v, off, dec ? 1 : 0,
-                       drop(site0 + 0), s.P, s.att);
+                       drop(site0 + 0), s.P, s.att, att16 ? 16 : 0);
     ST_LAUNCH_CHECK();
     ST_TRY(c.lin(s.att, y.wo, y.bo, w.ta, rows, 256, 256));
     hipLaunchKernelGGL(ae_resid_kernel, ROWS4(rows), s.x_in, w.ta, pos, row_sent, rows, drop(site0 + 1), s.x1);
@@ -822,7 +1251,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     ST_TRY(c.lin_bwd(w.ta, s.h, y.w2, w.th, 0, (float*)gy.w2, (float*)gy.b2, rows, 256, dff));
     hipLaunchKernelGGL(ae_relu_drop_bwd_kernel, ELEMS((long)rows * dff), w.th, s.h, (long)rows * dff, scale);
     ST_TRY(c.lin_bwd(w.th, s.n2, y.w1, w.tb, 0, (float*)gy.w1, (float*)gy.b1, rows, dff, 256));
-    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, xm, y.ln2_a, rows, dx, 1, (float*)gy.ln2_a, (float*)gy.ln2_b);
+    ST_TRY(c.ln_bwd(w.tb, xm, y.ln2_a, rows, dx, 1, (float*)gy.ln2_a, (float*)gy.ln2_b));
     if (dec) {
       // source attention: x2 = x1 + drop(u Wo^T + bo), u = c[sentence] * head factor; no gradient reaches q / k / norm
       hipLaunchKernelGGL(ae_resid_bwd_kernel, ROWS4(rows), dx, pos, row_sent, rows, drop(site0 + 3), w.ta);
@@ -833,13 +1262,16 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     // self-attention sublayer
     hipLaunchKernelGGL(ae_resid_bwd_kernel, ROWS4(rows), dx, pos, row_sent, rows, drop(site0 + 1), w.ta);
     ST_TRY(c.lin_bwd(w.ta, s.att, y.wo, w.tb, 0, (float*)gy.wo, (float*)gy.bo, rows, 256, 256));
+    if (att16)
+      hipLaunchKernelGGL(ae_attn16_bwd_kernel, dim3(n_sent), dim3(256), 0, c.st, s.q, s.k, s.v, s.P, w.tb, off, dec ? 1 : 0, drop(site0 + 0),
+                         w.ta, w.tc, w.td);
     hipLaunchKernelGGL(ae_attn_bwd_kernel, dim3(n_sent, 4), dim3(64), att_bwd_lds, c.st, s.q, s.k, s.v, s.P, w.tb, off, dec ? 1 : 0,
-                       drop(site0 + 0), w.ta, w.tc, w.td);
+                       drop(site0 + 0), w.ta, w.tc, w.td, att16 ? 16 : 0);
     ST_LAUNCH_CHECK();
     ST_TRY(c.lin_bwd(w.ta, s.n0, y.wq, w.tb, 0, (float*)gy.wq, (float*)gy.bq, rows, 256, 256));
     ST_TRY(c.lin_bwd(w.tc, s.n0, y.wk, w.tb, 1, (float*)gy.wk, (float*)gy.bk, rows, 256, 256));
     ST_TRY(c.lin_bwd(w.td, s.n0, y.wv, w.tb, 1, (float*)gy.wv, (float*)gy.bv, rows, 256, 256));
-    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, s.x_in, y.ln0_a, rows, dx, 1, (float*)gy.ln0_a, (float*)gy.ln0_b);
+    ST_TRY(c.ln_bwd(w.tb, s.x_in, y.ln0_a, rows, dx, 1, (float*)gy.ln0_a, (float*)gy.ln0_b));
     ST_LAUNCH_CHECK();
     return ST_OK;
   };
@@ -882,7 +1314,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     ST_TRY(c.lin_bwd(w.logits, w.d_xn, p->gen_w, w.tb, 0, (float*)g->gen_w, (float*)g->gen_b, Rd, V, 256));
     // the final norm's input is still needed by its backward: keep it in td
     ST_HIP(hipMemcpyAsync(w.td, w.d_x, (size_t)Rd * 1024, hipMemcpyDeviceToDevice, c.st));
-    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, w.td, p->dec_norm_a, Rd, dx, 0, (float*)g->dec_norm_a, (float*)g->dec_norm_b);
+    ST_TRY(c.ln_bwd(w.tb, w.td, p->dec_norm_a, Rd, dx, 0, (float*)g->dec_norm_a, (float*)g->dec_norm_b));
     ST_LAUNCH_CHECK();
     for (int l = L - 1; l >= 0; --l)
       ST_TRY(layer_bwd(p->dec[l], g->dec[l], w.dec[l], dx, Rd, B, dec_off, dec_pos, w.d_row_sent, true, 100 + 6 * l, w.lat, w.dlat));
@@ -894,7 +1326,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     float* dx = w.e_x;
     ST_HIP(hipMemcpyAsync(w.td, w.e_x, (size_t)Re * 1024, hipMemcpyDeviceToDevice, c.st));
     hipLaunchKernelGGL(ae_latent_bwd_kernel, dim3(Se), dim3(256), 0, c.st, w.e_y, w.dlat, enc_off, Se, w.tb);
-    hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(64), dim3(256), 0, c.st, w.tb, w.td, p->enc_norm_a, Re, dx, 0, (float*)g->enc_norm_a, (float*)g->enc_norm_b);
+    ST_TRY(c.ln_bwd(w.tb, w.td, p->enc_norm_a, Re, dx, 0, (float*)g->enc_norm_a, (float*)g->enc_norm_b));
     ST_LAUNCH_CHECK();
     for (int l = L - 1; l >= 0; --l)
       ST_TRY(layer_bwd(p->enc[l], g->enc[l], w.enc[l], dx, Re, Se, enc_off, enc_pos, w.e_row_sent, false, 10 + 4 * l, nullptr, nullptr));
