@@ -52,6 +52,20 @@ __device__ __forceinline__ float drop_factor(const Drop& d, uint64_t idx) {
   return u >= d.p ? d.scale : 0.0f;
 }
 
+// sum over nz slices of n values each, slice z at src + z * stride: 64 values per workgroup, the slices in four contiguous
+// groups (one per wave) added in index order, the four group sums added in index order: a fixed tree
+__device__ __forceinline__ float slices_sum64(const float* __restrict__ src, size_t stride, int nz, size_t e, bool ok, float (&red)[4][64]) {
+  const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int per = (nz + 3) / 4, z0 = g * per, z1 = min(nz, z0 + per);
+  float s = 0.0f;
+  if (ok) {
+#pragma unroll 8
+    for (int z = z0; z < z1; ++z) s += src[(size_t)z * stride + e];
+  }
+  red[g][l] = s;
+  __syncthreads();
+  return (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+}
 // ------------------------------------------------------------------------------------------------
 // C[i,j] (+)= bias[j] + sum_r A(i,r) B(r,j),  A(i,r) = A[i*sai + r*sar],  B(r,j) = B[r*sbr + j*sbj]
 // ------------------------------------------------------------------------------------------------
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256) void ae_slab_sum_kernel(GArgs a, const float* 
 // v_mfma_f32_32x32x2_f32 wants them (lane = output index, lane half = contraction index): every operand register is one
 // coalesced dword load (two rows of 32 consecutive floats per wave), no LDS, no barrier.  A wave owns a 64 x 64 tile
 // (4 accumulators), a workgroup 128 x 128 (the two waves sharing an operand meet in the vector L1); operands of the next
-// 16 rows are in flight under the 32 MFMAs of the current 16.  The contraction is cut into nz slices of whole 16-row
+// 8 rows are in flight under the 16 MFMAs of the current 8.  The contraction is cut into nz slices of whole 8-row
 // batches, one workgroup per (tile, slice), the tiles of a slice on ONE XCD (they read the same rows: its L2 serves the
 // second reader); partial products go to slab[z][i][j] and ae_dw_sum_kernel adds them in slice order (fixed order:
 // results do not depend on scheduling).  Out-of-range output columns read a clamped address: their garbage only
@@ -178,7 +192,7 @@ struct DwArgs {
   int nz, per, tiles_n, tiles;
 };
 #ifndef DW_U
-#define DW_U 8  /* contraction pairs per batch: 16 rows */
+#define DW_U 4  /* contraction pairs per batch: 8 rows (8: 214 us per launch at 3 waves per SIMD, 6: 173, 4: 152 at 4 waves) */
 #endif
 #ifdef DW_WITH_FENCE
 #define DW_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -188,7 +202,7 @@ struct DwArgs {
 // VEC 2 (M, N even): lane l of a half holds outputs 2 l and 2 l + 1 of its 64 and loads them as one dwordx2 (half the
 // load instructions: 190 against 209 us per launch); VEC 1: outputs l and l + 32, any M, N (the generator's odd vocabulary)
 template <int VEC>
-__global__ __launch_bounds__(256) void ae_dw_kernel(DwArgs a) {
+__global__ __launch_bounds__(256, 4) void ae_dw_kernel(DwArgs a) {
   const int nb = gridDim.x;  // a multiple of 8
   const int vid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
   if (vid >= a.tiles * a.nz) return;
@@ -214,6 +228,11 @@ __global__ __launch_bounds__(256) void ae_dw_kernel(DwArgs a) {
   float ca0[DW_U], ca1[DW_U], cb0[DW_U], cb1[DW_U], na0[DW_U], na1[DW_U], nb0[DW_U], nb1[DW_U];
   const int n_full = r_hi > r_lo ? (r_hi - r_lo) / (2 * DW_U) : 0;
   auto fetch = [&](float (&x0)[DW_U], float (&x1)[DW_U], float (&y0)[DW_U], float (&y1)[DW_U]) {
+#ifdef DW_ABLATE_LOADS
+#pragma unroll
+    for (int u = 0; u < DW_U; ++u) { x0[u] = sa0 + u; x1[u] = sa1; y0[u] = 1.0f; y1[u] = 2.0f; }
+    return;
+#endif
 #pragma unroll
     for (int u = 0; u < DW_U; ++u) {
       if constexpr (VEC == 2) {
@@ -229,6 +248,11 @@ __global__ __launch_bounds__(256) void ae_dw_kernel(DwArgs a) {
     pa0 += DW_U * sa; pa1 += DW_U * sa; pb0 += DW_U * sb; pb1 += DW_U * sb;
   };
   auto mac = [&](const float (&x0)[DW_U], const float (&x1)[DW_U], const float (&y0)[DW_U], const float (&y1)[DW_U]) {
+#ifdef DW_ABLATE_MFMA
+#pragma unroll
+    for (int u = 0; u < DW_U; ++u) { sa0 += x0[u] * y0[u]; sa1 += x1[u] * y1[u]; }
+    return;
+#endif
 #pragma unroll
     for (int u = 0; u < DW_U; ++u) {
       acc[0][0] = mfma32(x0[u], y0[u], acc[0][0]);
@@ -288,6 +312,9 @@ __global__ __launch_bounds__(256) void ae_dw_kernel(DwArgs a) {
         if (i < a.M) out[(size_t)i * a.N + j] = acc[q][p][r];
       }
     }
+#ifdef DW_ABLATE_MFMA
+  acc[0][0][0] = sa0 + sa1;
+#endif
   if (want_db) {  // lane half h holds the rows of parity h: even rows + odd rows
     sa0 += __shfl_down(sa0, 32);
     sa1 += __shfl_down(sa1, 32);
@@ -297,20 +324,112 @@ __global__ __launch_bounds__(256) void ae_dw_kernel(DwArgs a) {
     }
   }
 }
-// C[i][j] = sum_z slab[z][i][j]; db[i] = sum_z dbslab[z][i]; slices added in index order
+// The same product with the workgroup's operands SHARED through LDS (M, N multiples of 128): the direct form above has
+// each of the four waves load its own 64 + 64 columns, so every operand element is requested twice per workgroup, and
+// measured memory-bound on exactly that (ablations at 256 x 256 x 108 k: MFMAs alone 108 us, loads alone 79 us, together
+// 152 - 214 us).  Here 256 threads load a 16-row chunk of the 128 + 128 columns once (four coalesced 16-byte loads per
+// thread, in flight under the MFMAs of the previous chunk), park it in one of two LDS buffers, and every wave reads its
+// operand pairs from there (ds_read_b64, lane l of a half = outputs 2 l, 2 l + 1: 256 contiguous bytes per half-wave,
+// conflict-free without padding).  One barrier per chunk.
+#define DWL_ROWS 16
+__global__ __launch_bounds__(256, 4) void ae_dw_lds_kernel(DwArgs a) {
+  __shared__ __align__(16) float sA[2][DWL_ROWS][128], sB[2][DWL_ROWS][128];
+  const int nb = gridDim.x;  // a multiple of 8
+  const int vid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  if (vid >= a.tiles * a.nz) return;
+  const int tile = vid % a.tiles, z = vid / a.tiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int wi = wave >> 1, wc = wave & 1;
+  const int i0 = (tile / a.tiles_n) * 128, j0 = (tile % a.tiles_n) * 128;
+  const int r_lo = z * a.per, r_hi = min(a.R, r_lo + a.per);
+  const bool want_db = a.dbslab && (tile % a.tiles_n) == 0 && wc == 0;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][p][r] = 0.0f;
+  float sa0 = 0.0f, sa1 = 0.0f;
+  // staging: float4 f = tid + 256 k of a chunk's [16][32] float4s, k = 0, 1
+  const int srow = tid >> 5, scol = 4 * (tid & 31);
+  const float* ga = a.A + (size_t)i0 + scol;
+  const float* gb = a.B + (size_t)j0 + scol;
+  f32x4 ra[2], rb[2];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = r0 + srow + 8 * k;
+      ra[k] = rb[k] = f32x4{0, 0, 0, 0};
+      if (r < r_hi) {
+        ra[k] = *(const f32x4*)(ga + (size_t)r * a.lda);
+        rb[k] = *(const f32x4*)(gb + (size_t)r * a.ldb);
+      }
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      *(f32x4*)&sA[buf][srow + 8 * k][scol] = ra[k];
+      *(f32x4*)&sB[buf][srow + 8 * k][scol] = rb[k];
+    }
+  };
+  const int n_chunks = r_hi > r_lo ? (r_hi - r_lo + DWL_ROWS - 1) / DWL_ROWS : 0;
+  if (n_chunks > 0) {
+    fetch(r_lo);
+    park(0);
+  }
+  __syncthreads();
+  for (int b = 0; b < n_chunks; ++b) {
+    const int buf = b & 1;
+    if (b + 1 < n_chunks) fetch(r_lo + (b + 1) * DWL_ROWS);
+#pragma unroll
+    for (int u = 0; u < DWL_ROWS / 2; ++u) {
+      const float2 x = *(const float2*)&sA[buf][2 * u + half][wi * 64 + 2 * l31];
+      const float2 y = *(const float2*)&sB[buf][2 * u + half][wc * 64 + 2 * l31];
+      acc[0][0] = mfma32(x.x, y.x, acc[0][0]);
+      acc[0][1] = mfma32(x.x, y.y, acc[0][1]);
+      acc[1][0] = mfma32(x.y, y.x, acc[1][0]);
+      acc[1][1] = mfma32(x.y, y.y, acc[1][1]);
+      if (want_db) {
+        sa0 += x.x;
+        sa1 += x.y;
+      }
+    }
+    if (b + 1 < n_chunks) park(buf ^ 1);
+    __syncthreads();
+  }
+  float* out = a.slab + (size_t)z * a.M * a.N;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wi * 64 + 2 * mfma32_row(r, lane) + q;
+      const int j = j0 + wc * 64 + 2 * l31;
+      *(float2*)(out + (size_t)i * a.N + j) = float2{acc[q][0][r], acc[q][1][r]};
+    }
+  if (want_db) {  // lane half h holds the rows of parity h: even rows + odd rows
+    sa0 += __shfl_down(sa0, 32);
+    sa1 += __shfl_down(sa1, 32);
+    if (half == 0) {
+      a.dbslab[(size_t)z * a.M + i0 + wi * 64 + 2 * l31] = sa0;
+      a.dbslab[(size_t)z * a.M + i0 + wi * 64 + 2 * l31 + 1] = sa1;
+    }
+  }
+}
+// C[i][j] = sum_z slab[z][i][j]; db[i] = sum_z dbslab[z][i]
 __global__ __launch_bounds__(256) void ae_dw_sum_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab, int nz, int M,
                                                         int N, float* __restrict__ C, int ldc, float* __restrict__ db) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, mn = (size_t)M * N;
-  if (e < mn) {
-    float s = 0.0f;
-#pragma unroll 8
-    for (int z = 0; z < nz; ++z) s += slab[(size_t)z * mn + e];
-    C[(e / N) * ldc + (e % N)] = s;
-  } else if (e < mn + M && db) {
-    const int i = (int)(e - mn);
-    float s = 0.0f;
-    for (int z = 0; z < nz; ++z) s += dbslab[(size_t)z * M + i];
-    db[i] = s;
+  __shared__ float red[4][64];
+  const size_t mn = (size_t)M * N, nb_c = (mn + 63) / 64;
+  if (blockIdx.x < nb_c) {
+    const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slices_sum64(slab, mn, nz, e, e < mn, red);
+    if (threadIdx.x < 64 && e < mn) C[(e / N) * ldc + (e % N)] = s;
+  } else {
+    const size_t i = (size_t)(blockIdx.x - nb_c) * 64 + (threadIdx.x & 63);
+    const float s = slices_sum64(dbslab, (size_t)M, nz, i, i < (size_t)M, red);
+    if (threadIdx.x < 64 && i < (size_t)M) db[i] = s;
   }
 }
 
@@ -426,14 +545,15 @@ __global__ __launch_bounds__(256) void ae_ln_bwd_kernel(const float* __restrict_
   part[(size_t)blockIdx.x * 512 + c] = (sa[0][c] + sa[1][c]) + (sa[2][c] + sa[3][c]);
   part[(size_t)blockIdx.x * 512 + 256 + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
 }
-__global__ __launch_bounds__(512) void ae_ln_bwd_finish_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ da,
+__global__ __launch_bounds__(256) void ae_ln_bwd_finish_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ da,
                                                                float* __restrict__ db) {
-  const int c = threadIdx.x;  // 0 .. 255: da, 256 .. 511: db
-  float s = 0.0f;
-#pragma unroll 8
-  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 512 + c];
-  float* o = c < 256 ? da + c : db + (c - 256);
-  *o += s;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);  // 0 .. 255: da, 256 .. 511: db
+  const float s = slices_sum64(part, 512, nblocks, (size_t)c, true, red);
+  if (threadIdx.x < 64) {
+    float* o = c < 256 ? da + c : db + (c - 256);
+    *o += s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1096,7 +1216,7 @@ struct Ctx {
     ST_LAUNCH_CHECK();
     return ST_OK;
   }
-  // dW[M, N] = dY[R, M]^T X[R, N] and db = column sums of dY, on ae_dw_kernel (slices of the contraction until ~ 3 workgroups per CU)
+  // dW[M, N] = dY[R, M]^T X[R, N] and db = column sums of dY, on ae_dw_kernel (slices of the contraction until ~ 4 workgroups per CU)
   bool dw_ok(int M, int N, int R) const {
     static const bool off = getenv("ST_AE_NO_DW") != nullptr;
     return !off && slab && R >= 256 && (size_t)M * N + M <= slab_floats;
@@ -1106,20 +1226,23 @@ struct Ctx {
     a.A = dY; a.B = X; a.M = M; a.N = N; a.R = R; a.lda = M; a.ldb = N;
     a.tiles_n = (N + 127) / 128;
     a.tiles = a.tiles_n * ((M + 127) / 128);
-    int nz = std::max(1, std::min((768 + a.tiles - 1) / a.tiles, R / 64));
+    int nz = std::max(1, std::min((1024 + a.tiles - 1) / a.tiles, R / 64));  // ~ 4 workgroups per CU (4 waves per SIMD at 120 registers)
     while (nz > 1 && (size_t)nz * ((size_t)M * N + M) > slab_floats) --nz;
     a.per = ((R + nz - 1) / nz + 2 * DW_U - 1) / (2 * DW_U) * (2 * DW_U);
     a.nz = (R + a.per - 1) / a.per;
     a.slab = slab;
     a.dbslab = db ? slab + (size_t)a.nz * M * N : nullptr;
     const int blocks = (a.tiles * a.nz + 7) / 8 * 8;
-    if (((M | N) & 1) == 0 && (((uintptr_t)dY | (uintptr_t)X) & 7) == 0)
+    static const bool direct = getenv("ST_AE_DW_DIRECT") != nullptr;
+    if (!direct && ((M | N) & 127) == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0)
+      hipLaunchKernelGGL(ae_dw_lds_kernel, dim3(blocks), dim3(256), 0, st, a);
+    else if (((M | N) & 1) == 0 && (((uintptr_t)dY | (uintptr_t)X) & 7) == 0)
       hipLaunchKernelGGL(ae_dw_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL(ae_dw_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
-    const size_t e = (size_t)M * N + (db ? M : 0);
-    hipLaunchKernelGGL(ae_dw_sum_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, (const float*)a.slab, (const float*)a.dbslab,
-                       a.nz, M, N, dW, N, db);
+    const size_t sum_blocks = ((size_t)M * N + 63) / 64 + (db ? (M + 63) / 64 : 0);
+    hipLaunchKernelGGL(ae_dw_sum_kernel, dim3((unsigned)sum_blocks), dim3(256), 0, st, (const float*)a.slab, (const float*)a.dbslab, a.nz,
+                       M, N, dW, N, db);
     ST_LAUNCH_CHECK();
     return ST_OK;
   }
@@ -1128,7 +1251,7 @@ struct Ctx {
     int nb = std::max(1, std::min(1024, (rows + 3) / 4));
     while (nb > 1 && (size_t)nb * 512 > slab_floats) --nb;
     hipLaunchKernelGGL(ae_ln_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, x, a, rows, dx, accumulate, slab);
-    hipLaunchKernelGGL(ae_ln_bwd_finish_kernel, dim3(1), dim3(512), 0, st, (const float*)slab, nb, da, db);
+    hipLaunchKernelGGL(ae_ln_bwd_finish_kernel, dim3(8), dim3(256), 0, st, (const float*)slab, nb, da, db);
     ST_LAUNCH_CHECK();
     return ST_OK;
   }
