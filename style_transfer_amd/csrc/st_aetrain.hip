@@ -1097,7 +1097,7 @@ struct LayerSave {
 #define AE_DW_SLAB_FLOATS (1u << 23)  /* 32 MB: 128 slices of a 256 x 256 gradient, 32 of a 256 x 1024 one */
 struct Ws {
   // encoder (Re rows), decoder (Rd rows)
-  int32_t *e_row_sent, *d_row_sent;
+  int32_t *e_row_sent, *d_row_sent, *flags;
   LayerSave enc[ST_MAX_LAYERS], dec[ST_MAX_LAYERS];
   float *e_x, *e_y, *lat, *dlat;                 // encoder output before / after the final norm, latents and their gradient
   float *d_x, *d_xn, *logits, *row_loss, *cc[ST_MAX_LAYERS], *dcc;
@@ -1117,6 +1117,7 @@ Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
   Arena a{base, 0};
   const int L = p->n_layers, dff = p->d_ff, V = p->vocab;
   const int R = Re > Rd ? Re : Rd;
+  w.flags = (int32_t*)a.f(64);
   w.e_row_sent = (int32_t*)a.f(Re);
   w.d_row_sent = (int32_t*)a.f(Rd);
   for (int l = 0; l < L; ++l) {
@@ -1170,6 +1171,26 @@ __global__ __launch_bounds__(256) void ae_pack_kernel(const float* __restrict__ 
   *(f32x4*)(out + o * 4) = v;
 }
 
+// the exact-f32 redo of a forward product whose split-f16 run saw an activation outside the f16 range: packs the f32 image
+// and opens the redo's row count; in range (always, in practice) it packs nothing and the redo's workgroups find 0 rows
+__global__ __launch_bounds__(256) void ae_redo_pack_kernel(const int* __restrict__ flag, int rows, int* __restrict__ redo_rows,
+                                                           const float* __restrict__ src, int N, int K, float* __restrict__ out) {
+  const bool redo = *flag != 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *redo_rows = redo ? rows : 0;
+  if (!redo) return;
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int kgs = K >> 3;
+  const size_t total = (size_t)((N + 31) / 32) * kgs * 64;
+  if (o >= total) return;
+  const int lane = (int)(o & 63);
+  const int kg = (int)((o >> 6) % kgs);
+  const int blk = (int)((o >> 6) / kgs);
+  const int row = blk * 32 + (lane & 31);
+  f32x4 v = {0, 0, 0, 0};
+  if (row < N) v = *(const f32x4*)(src + (size_t)row * K + kg * 8 + 4 * (lane >> 5));
+  *(f32x4*)(out + o * 4) = v;
+}
+
 struct Ctx {
   hipStream_t st;
   int rc;
@@ -1177,6 +1198,40 @@ struct Ctx {
   size_t slab_floats;
   float* wpack;
   size_t wpack_floats;
+  int* flags;  // [0]: a forward product saw an activation outside the f16 range (sticky within the step), [1]: rows of the f32 redo
+  // FORWARD products Y = X W^T + b on the split-f16 row-panel kernels (f32-grade: three f16 products per term, f32
+  // accumulation, st_common.h; ~ 3x the exact-f32 rate): activations and weights are O(1) there.  The backward products
+  // stay exact f32: gradients of 1e-7 .. 1e-3 sit below the f16 subnormal floor.  Each product is followed by its exact-f32
+  // form gated on the device by the range flag (0 rows unless an activation left the f16 range: then every row again).
+  bool h_ok(int rows, int N, int K) const {
+    static const bool off = getenv("ST_AE_F32_FWD") != nullptr;
+    return !off && flags && rp_ok(rows, N, K) && K % 16 == 0;
+  }
+  int rp_lin_h(const float* X, const float* W, const float* bias, float* Y, int rows, int N, int K) {
+    const size_t th = (size_t)((N + 31) / 32) * (K >> 4) * 64;
+    hipLaunchKernelGGL(pack_weight_h_kernel<0>, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, W, N, K, wpack);
+    ST_LAUNCH_CHECK();
+    GemmArgs g = {};
+    g.fmt = ST_GEMM_F16X3; g.X = X; g.n_host = rows; g.W = wpack; g.bias = bias; g.N = N; g.out = Y; g.ldo = N;
+    g.range_flag = flags;
+    if (K == 256) {
+      const int splits = rp_splits(rows, N, 8, rp_nw(ST_GEMM_F16X3, 8));
+      if (N % 32 == 0)  // the 16x16x32 projection kernel of the attack path (needs whole 32-column blocks)
+        ST_TRY(launch_rp_lin_pipelined<EPI_BIAS>(g, rows, splits, st));
+      else
+        ST_TRY((launch_rp<EPI_BIAS, 8>(g, rows, splits, st)));
+    } else {
+      g.K = K;
+      ST_TRY(launch_rp_kchunk<EPI_BIAS>(g, rows, st, 1));
+    }
+    const size_t tf = (size_t)((N + 31) / 32) * (K >> 3) * 64;
+    hipLaunchKernelGGL(ae_redo_pack_kernel, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, st, (const int*)flags, rows, flags + 1, W, N, K,
+                       wpack);
+    ST_LAUNCH_CHECK();
+    g.fmt = ST_GEMM_F32; g.range_flag = nullptr; g.n_dev = flags + 1;
+    if (K == 256) return launch_rp<EPI_BIAS, 8>(g, rows, rp_splits(rows, N, 8, 8), st);
+    return launch_rp_kchunk<EPI_BIAS>(g, rows, st, 1);
+  }
   // Y[rows, N] (+)= X[rows, K] . W'^T + bias with W'[n][k] = Wsrc[n * sn + k * sk], on the exact-f32 ROW-PANEL kernels
   // (st_rowpanel.h: 64-row panel of X in LDS, fragment-packed W straight from L2; 110 - 130 TFLOP/s where the strided
   // kernel below reaches 45).  The weights change every step, so the image is packed in front of every product (a few
@@ -1267,6 +1322,7 @@ struct Ctx {
   }
   // Y[rows,N] = X[rows,K] W^T + b      (W row-major [N,K])
   int lin(const float* X, const float* W, const float* b, float* Y, int rows, int N, int K) {
+    if (h_ok(rows, N, K)) return rp_lin_h(X, W, b, Y, rows, N, K);
     if (rp_ok(rows, N, K)) return rp_lin(X, W, K, 1, b, Y, rows, N, K, 0);
     return gemm(X, K, 1, W, 1, K, Y, N, b, rows, N, K, 0);
   }
@@ -1317,7 +1373,8 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     st_set_error("st_ae_train_step: workspace too small: need %zu bytes, have %zu", w.total, workspace_bytes);
     return ST_ENOMEM;
   }
-  Ctx c{(hipStream_t)stream, 0, w.slab, w.slab_floats, w.wpack, w.wpack_floats};
+  Ctx c{(hipStream_t)stream, 0, w.slab, w.slab_floats, w.wpack, w.wpack_floats, (int*)w.flags};
+  ST_HIP(hipMemsetAsync(w.flags, 0, 256, c.st));
   const int Re = n_enc_rows, Se = n_enc_sent, Rd = n_dec_rows, L = p->n_layers, dff = p->d_ff, V = p->vocab;
   const int n_views = Se / B - 1;
   auto drop = [&](uint32_t site) { return Drop{seed, drop_p, drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f, site}; };
