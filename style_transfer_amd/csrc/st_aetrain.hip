@@ -29,6 +29,25 @@
   } while (0)
 #endif
 
+// Kernel-form switches of the step (ints in the library so that tests can flip them: tests/test_gpu_train.py; the
+// environment variables of INTEGRATION.md section D set their start values, read once).  Every form computes the same
+// function; summation orders differ.
+int g_ae_fwd_h = 1;       // ST_AE_F32_FWD -> 0: forward products in exact f32
+int g_ae_force_redo = 0;  // tests: the range flag starts at 1, so every split-f16 forward product is redone in exact f32
+int g_ae_rp = 1;          // ST_AE_NO_RP -> 0: strided GEMM for forward and dX
+int g_ae_dw = 2;          // ST_AE_NO_DW -> 0: strided GEMM + column sums; ST_AE_DW_DIRECT -> 1: operands straight from global memory; 2: through LDS
+int g_ae_att16 = 1;       // ST_AE_NO_ATT16 -> 0: lane-per-row attention kernels for every sentence
+static void ae_env() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (getenv("ST_AE_F32_FWD")) g_ae_fwd_h = 0;
+  if (getenv("ST_AE_NO_RP")) g_ae_rp = 0;
+  if (getenv("ST_AE_DW_DIRECT")) g_ae_dw = 1;
+  if (getenv("ST_AE_NO_DW")) g_ae_dw = 0;
+  if (getenv("ST_AE_NO_ATT16")) g_ae_att16 = 0;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -475,10 +494,14 @@ __global__ __launch_bounds__(256) void ae_embed_kernel(const float* __restrict__
   for (int j = 0; j < 4; ++j) v[j] *= drop_factor(dr, base + j);
   *(f32x4*)(x + (size_t)r * 256 + lane * 4) = v;
 }
-// d emb[token] += sqrt(d) * dropout'(dx)
+// d emb[token] += sqrt(d) * dropout'(dx), scattered over the rows of each token.  The sums are taken in 64-bit FIXED POINT
+// (units of 2^-44: exact integer atomics, so the result does not depend on the order the rows arrive in -- float atomics
+// made the embedding gradient the one tensor of the step that differed in its last bits from run to run); range
+// +-2^19 per element, resolution 5.7e-14; ae_embed_finish_kernel converts and adds into the gradient.
+#define AE_EMB_FIX 17592186044416.0 /* 2^44 */
 __global__ __launch_bounds__(256) void ae_embed_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ tok,
                                                            const int32_t* __restrict__ pos, const int32_t* __restrict__ row_sent,
-                                                           int n, int vocab, Drop dr, float* __restrict__ demb) {
+                                                           int n, int vocab, Drop dr, unsigned long long* __restrict__ acc) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const int lane = threadIdx.x & 63;
@@ -486,7 +509,17 @@ __global__ __launch_bounds__(256) void ae_embed_bwd_kernel(const float* __restri
   const f32x4 g = *(const f32x4*)(dx + (size_t)r * 256 + lane * 4);
   const uint64_t base = ((uint64_t)row_sent[r] * 64 + pos[r]) * 256 + lane * 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) atomicAdd(demb + (size_t)t * 256 + lane * 4 + j, 16.0f * g[j] * drop_factor(dr, base + j));
+  for (int j = 0; j < 4; ++j) {
+    const double v = fmin(fmax((double)(16.0f * g[j] * drop_factor(dr, base + j)), -524287.0), 524287.0) * AE_EMB_FIX;
+    const long long q = __double2ll_rn(v);
+    if (q != 0) atomicAdd(acc + (size_t)t * 256 + lane * 4 + j, (unsigned long long)q);
+  }
+}
+__global__ __launch_bounds__(256) void ae_embed_finish_kernel(const unsigned long long* __restrict__ acc, long n, float* __restrict__ demb) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const long long q = (long long)acc[e];
+  if (q != 0) demb[e] += (float)((double)q * (1.0 / AE_EMB_FIX));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1099,6 +1132,7 @@ struct Ws {
   // encoder (Re rows), decoder (Rd rows)
   int32_t *e_row_sent, *d_row_sent, *flags;
   LayerSave enc[ST_MAX_LAYERS], dec[ST_MAX_LAYERS];
+  unsigned long long* emb_acc;                    // [V, 256] fixed-point sums of the embedding gradient
   float *e_x, *e_y, *lat, *dlat;                 // encoder output before / after the final norm, latents and their gradient
   float *d_x, *d_xn, *logits, *row_loss, *cc[ST_MAX_LAYERS], *dcc;
   float *ta, *tb, *tc, *td, *th;                 // scratch activations / gradients [rows, 256] x4, [rows, d_ff]
@@ -1131,6 +1165,7 @@ Ws carve(const StAeParams* p, int Re, int Se, int Rd, int B, char* base) {
     d.u = a.f((size_t)Rd * 256); d.x2 = a.f((size_t)Rd * 256); d.n2 = a.f((size_t)Rd * 256); d.h = a.f((size_t)Rd * dff);
     w.cc[l] = a.f((size_t)B * 256);
   }
+  w.emb_acc = (unsigned long long*)a.f((size_t)V * 256 * 2);
   w.e_x = a.f((size_t)Re * 256); w.e_y = a.f((size_t)Re * 256);
   w.lat = a.f((size_t)Se * 256); w.dlat = a.f((size_t)Se * 256);
   w.d_x = a.f((size_t)Rd * 256); w.d_xn = a.f((size_t)Rd * 256);
@@ -1204,8 +1239,7 @@ struct Ctx {
   // stay exact f32: gradients of 1e-7 .. 1e-3 sit below the f16 subnormal floor.  Each product is followed by its exact-f32
   // form gated on the device by the range flag (0 rows unless an activation left the f16 range: then every row again).
   bool h_ok(int rows, int N, int K) const {
-    static const bool off = getenv("ST_AE_F32_FWD") != nullptr;
-    return !off && flags && rp_ok(rows, N, K) && K % 16 == 0;
+    return g_ae_fwd_h && flags && rp_ok(rows, N, K) && K % 16 == 0;
   }
   int rp_lin_h(const float* X, const float* W, const float* bias, float* Y, int rows, int N, int K) {
     const size_t th = (size_t)((N + 31) / 32) * (K >> 4) * 64;
@@ -1237,8 +1271,7 @@ struct Ctx {
   // kernel below reaches 45).  The weights change every step, so the image is packed in front of every product (a few
   // microseconds); contraction 256, or a multiple of 256 with a 256-wide result.
   bool rp_ok(int rows, int N, int K) const {
-    static const bool off = getenv("ST_AE_NO_RP") != nullptr;
-    return !off && wpack && rows >= 256 && ((K == 256) || (K % 256 == 0 && N == 256)) && rp_packed_floats(N, K) <= wpack_floats;
+    return g_ae_rp && wpack && rows >= 256 && ((K == 256) || (K % 256 == 0 && N == 256)) && rp_packed_floats(N, K) <= wpack_floats;
   }
   int rp_lin(const float* X, const float* Wsrc, long sn, long sk, const float* bias, float* Y, int rows, int N, int K, int acc) {
     const size_t total = (size_t)((N + 31) / 32) * (K >> 3) * 64;
@@ -1273,8 +1306,7 @@ struct Ctx {
   }
   // dW[M, N] = dY[R, M]^T X[R, N] and db = column sums of dY, on ae_dw_kernel (slices of the contraction until ~ 4 workgroups per CU)
   bool dw_ok(int M, int N, int R) const {
-    static const bool off = getenv("ST_AE_NO_DW") != nullptr;
-    return !off && slab && R >= 256 && (size_t)M * N + M <= slab_floats;
+    return g_ae_dw && slab && R >= 256 && (size_t)M * N + M <= slab_floats;
   }
   int dw(const float* dY, const float* X, float* dW, float* db, int M, int N, int R) {
     DwArgs a = {};
@@ -1288,8 +1320,7 @@ struct Ctx {
     a.slab = slab;
     a.dbslab = db ? slab + (size_t)a.nz * M * N : nullptr;
     const int blocks = (a.tiles * a.nz + 7) / 8 * 8;
-    static const bool direct = getenv("ST_AE_DW_DIRECT") != nullptr;
-    if (!direct && ((M | N) & 127) == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0)
+    if (g_ae_dw == 2 && ((M | N) & 127) == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0)
       hipLaunchKernelGGL(ae_dw_lds_kernel, dim3(blocks), dim3(256), 0, st, a);
     else if (((M | N) & 1) == 0 && (((uintptr_t)dY | (uintptr_t)X) & 7) == 0)
       hipLaunchKernelGGL(ae_dw_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
@@ -1357,6 +1388,7 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
                                 const int32_t* dec_off, int n_dec_rows, int B, float bata, float tau, float smoothing,
                                 float drop_p, uint64_t seed, float* losses_out, void* workspace, size_t workspace_bytes,
                                 void* stream) {
+  ae_env();
   ST_CHECK_ARG(p && g && grads_flat && n_params > 0, "NULL parameter / gradient structs");
   ST_CHECK_ARG(p->d_model == ST_D && p->n_heads == 4, "d_model=%d n_heads=%d unsupported (256, 4)", p->d_model, p->n_heads);
   ST_CHECK_ARG(p->n_layers >= 1 && p->n_layers <= ST_MAX_LAYERS && p->d_ff > 0 && p->vocab >= 4, "n_layers=%d d_ff=%d vocab=%d",
@@ -1374,12 +1406,13 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     return ST_ENOMEM;
   }
   Ctx c{(hipStream_t)stream, 0, w.slab, w.slab_floats, w.wpack, w.wpack_floats, (int*)w.flags};
-  ST_HIP(hipMemsetAsync(w.flags, 0, 256, c.st));
+  ST_HIP(hipMemsetAsync(w.flags, g_ae_force_redo ? 1 : 0, 4, c.st));  // (byte fill: 0 or 0x01010101, any non-zero value flags)
+  ST_HIP(hipMemsetAsync(w.flags + 1, 0, 252, c.st));
   const int Re = n_enc_rows, Se = n_enc_sent, Rd = n_dec_rows, L = p->n_layers, dff = p->d_ff, V = p->vocab;
   const int n_views = Se / B - 1;
   auto drop = [&](uint32_t site) { return Drop{seed, drop_p, drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f, site}; };
   const size_t att_fwd_lds = 2 * ATT_TILE * 4, att_bwd_lds = 6 * ATT_TILE * 4;
-  static const bool att16 = getenv("ST_AE_NO_ATT16") == nullptr;  // sentences of <= 16 positions on the (row, quarter) kernels
+  const bool att16 = g_ae_att16 != 0;  // sentences of <= 16 positions on the (row, quarter) kernels
   ST_ENSURE_LDS(ae_attn_bwd_kernel, (int)att_bwd_lds);
 
   ST_HIP(hipMemsetAsync(grads_flat, 0, (size_t)n_params * 4, c.st));
@@ -1498,7 +1531,8 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     ST_LAUNCH_CHECK();
     for (int l = L - 1; l >= 0; --l)
       ST_TRY(layer_bwd(p->dec[l], g->dec[l], w.dec[l], dx, Rd, B, dec_off, dec_pos, w.d_row_sent, true, 100 + 6 * l, w.lat, w.dlat));
-    hipLaunchKernelGGL(ae_embed_bwd_kernel, ROWS4(Rd), dx, dec_tokens, dec_pos, w.d_row_sent, Rd, V, drop(2), (float*)g->emb);
+    ST_HIP(hipMemsetAsync(w.emb_acc, 0, (size_t)V * 256 * 8, c.st));
+    hipLaunchKernelGGL(ae_embed_bwd_kernel, ROWS4(Rd), dx, dec_tokens, dec_pos, w.d_row_sent, Rd, V, drop(2), w.emb_acc);
     ST_LAUNCH_CHECK();
   }
   // ---------------- encoder backward ----------------
@@ -1510,7 +1544,8 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
     ST_LAUNCH_CHECK();
     for (int l = L - 1; l >= 0; --l)
       ST_TRY(layer_bwd(p->enc[l], g->enc[l], w.enc[l], dx, Re, Se, enc_off, enc_pos, w.e_row_sent, false, 10 + 4 * l, nullptr, nullptr));
-    hipLaunchKernelGGL(ae_embed_bwd_kernel, ROWS4(Re), dx, enc_tokens, enc_pos, w.e_row_sent, Re, V, drop(1), (float*)g->emb);
+    hipLaunchKernelGGL(ae_embed_bwd_kernel, ROWS4(Re), dx, enc_tokens, enc_pos, w.e_row_sent, Re, V, drop(1), w.emb_acc);
+    hipLaunchKernelGGL(ae_embed_finish_kernel, ELEMS((long)V * 256), (const unsigned long long*)w.emb_acc, (long)V * 256, (float*)g->emb);
     ST_LAUNCH_CHECK();
   }
   return ST_OK;

@@ -310,6 +310,63 @@ def test_ae_train_step_with_dropout_matches_the_oracle(ae_sd_torch, ae_sd):
     assert abs(keep_mask(seed, 11, np.arange(200000), 0.1).mean() - 0.9) < 5e-3
 
 
+# (switch, value, tolerance on every tensor's gradient relative to its norm).  Forms that re-order sums: 2e-5.  Forms that
+# change the FORWARD products' rounding (split f16 <-> exact f32, ~ 3e-7 relative on activations): 2e-2, because the step is
+# not continuous at that scale -- a pre-activation within 3e-7 of zero flips its ReLU, and one flip moves the first FFN's
+# weight gradient by ~ 1e-3 of its norm; the EXACT-f32 step answers a 3e-7 perturbation of its parameters with the same
+# 5e-3 jumps in the same tensors (tools/ae_fwd_format_probe2.py); on the reference's golden batch the two formats agree
+# to 2e-6 (tools/ae_fwd_format_probe.py) and both meet the reference's gradients to the same 1e-4.
+AE_FORMS = [("g_ae_att16", 0, 2e-5), ("g_ae_dw", 1, 2e-5), ("g_ae_dw", 0, 2e-5), ("g_ae_fwd_h", 0, 2e-2), ("g_ae_force_redo", 1, 2e-2),
+            ("g_ae_rp", 0, 2e-2)]
+
+
+def test_ae_train_step_kernel_forms_agree(ae_sd_torch):
+    """Every kernel form of the step kept behind a switch against the shipped ones, on a batch of
+    64 records whose sentences run from 3 to 30 tokens (so BOTH attention kernel families work on every launch: <= 16
+    positions on the (row, quarter) kernels, longer ones on the lane-per-row kernels) with dropout 0.1: losses 1e-5,
+    every tensor's gradient within the form's tolerance of its norm (AE_FORMS).  The forward's exact-f32 redo is forced
+    through the range flag and must give, bit for bit, the step whose forward is exact f32 throughout."""
+    import ctypes as C
+    import ae_train_common as AC
+    from style_transfer_amd import _lib
+    L = _lib.lib()
+    tr = _ae_trainer(ae_sd_torch, 0.1)
+    rng = np.random.default_rng(5)
+    sent = lambda: [int(t) for t in rng.integers(4, tr.vocab, int(rng.integers(17, 31) if rng.random() < 0.2 else rng.integers(3, 16)))]
+    B = 64
+    origin = [sent() for _ in range(B)]
+    views = [[sent() for _ in range(B)] for _ in range(10)]
+    assert max(len(s) for s in origin) > 16 and min(len(s) for s in origin) <= 16
+    batch = tr.pack(origin, views)
+
+    def run():
+        rec, con = tr.loss_and_grads(batch, seed=99)
+        return rec, con, tr.grads.clone()
+    rec0, con0, g0 = run()
+    assert np.isfinite(rec0) and np.isfinite(con0)
+    got = {}
+    for name, value, tol in AE_FORMS:
+        sw = C.c_int.in_dll(L, name)
+        old = sw.value
+        sw.value = value
+        try:
+            rec, con, g = run()
+        finally:
+            sw.value = old
+        got[(name, value)] = g
+        assert abs(rec - rec0) < 1e-5 * abs(rec0) and abs(con - con0) < 1e-5 * abs(con0), (name, value, rec, rec0, con, con0)
+        for i, n in enumerate(tr.names):
+            a, b = g[tr.offsets[i]:tr.offsets[i + 1]].double(), g0[tr.offsets[i]:tr.offsets[i + 1]].double()
+            nb = float(b.norm())
+            if AC.is_noise(n) or AC.is_zero(n):
+                assert float(a.norm()) < 1e-6 and nb < 1e-6, (name, value, n)
+            else:
+                assert float((a - b).norm()) < tol * nb, (name, value, n, float((a - b).norm()), nb)
+    assert torch.equal(got[("g_ae_force_redo", 1)], got[("g_ae_fwd_h", 0)]), "the forced exact-f32 redo differs from the exact-f32 forward"
+    rec1, con1, g1 = run()
+    assert rec1 == rec0 and con1 == con0 and torch.equal(g1, g0), "the shipped step is not bit-reproducible"
+
+
 def test_cli_train_ae_writes_the_reference_checkpoint(tmp_path, ae_sd_torch):
     """`main --train_ae` (the reference's train_ae_model_constraint branch, main.py:470-471): one epoch of two batches on
     ae_train_constraint{0,1}.json written from the test records; the checkpoint carries the reference's file name and key
