@@ -317,6 +317,189 @@ static int sl_bwd_fused(const float* Xrows, int rows, const float* W1packed, con
   return ST_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward on the same tiles (f16x3 format, Bq % 64 == 0, Bk % 256 == 0): S = panel . keys^T chunk by chunk as in
+// sl_bwd16_kernel, and instead of dS an online log-sum-exp per panel row (one exponential per logit: e = exp(-|s - m|)
+// rescales the sum or is the new term), taken from the previous chunk's accumulators in the shadow of the current
+// chunk's MFMAs.  partial[row][split] = (max, sum exp(s - max), s[target] or 0, 0): lse_merge_kernel's input, as the
+// 32x32x16 row-panel kernel with the LSE epilogue wrote it (135 us per 8192 x 8192 view there).
+// ------------------------------------------------------------------------------------------------
+struct SlfArgs {
+  const float* X;   // [n, 256] unit rows of the queries
+  int n;            // multiple of 64
+  const float* w1;  // packed f16x3 image of the keys' unit rows [Ncols][256]
+  int Ncols;        // multiple of 256
+  int chunks_per_split;
+  float scale;      // 1 / tau
+  int tgt_off;      // target column of row R: R + tgt_off
+  float4* partial;  // [n][gridDim.y]
+};
+#define SLF_LDS (64 * ST_LDA * 4 + 8 * 64 * 3 * 4)
+__global__ __launch_bounds__(512, 2) void sl_fwd16_kernel(SlfArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* P1 = smem;
+  float* red = smem + 64 * ST_LDA;  // [8 waves][64 rows][3]
+  const int m0 = blockIdx.x * 64;
+  const int nchunk = a.Ncols >> 8;
+  const int c_lo = blockIdx.y * a.chunks_per_split;
+  const int c_hi = min(nchunk, c_lo + a.chunks_per_split);
+  if (m0 >= a.n) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wlane = (g >> 1) * 128 + 32 * (g & 1) + r16;
+  auto W1p = [&](int c) { return (const f32x4*)a.w1 + (size_t)(c * 8 + wave) * 16 * 128 + wlane; };
+  f32x4 rw[2][4];
+  auto wfetch = [&](const f32x4* Wl, int d, f32x4 (&dst)[4]) {
+    dst[0] = Wl[d * 256];
+    dst[1] = Wl[d * 256 + 64];
+    dst[2] = Wl[d * 256 + 16];
+    dst[3] = Wl[d * 256 + 80];
+  };
+  float lm[4], ll[4], lt[4];
+  int tgt[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    lm[rt] = -INFINITY;
+    ll[rt] = 0.0f;
+    lt[rt] = 0.0f;
+    tgt[rt] = m0 + 16 * rt + r16 + a.tgt_off;
+  }
+  if (c_lo < c_hi) {
+    wfetch(W1p(c_lo), 0, rw[0]);
+    wfetch(W1p(c_lo), 1, rw[1]);
+    int bad = 0;
+    {
+      f32x4 xr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int f = tid + i * 512;
+        xr[i] = *(const f32x4*)(a.X + (size_t)(m0 + (f >> 6)) * 256 + (f & 63) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int f = tid + i * 512;
+        panel_store4_nb16(P1 + (f >> 6) * ST_LDA, f & 63, xr[i], bad);
+      }
+    }
+    (void)bad;  // unit rows lie in [-1, 1]
+    const float* A1 = P1 + r16 * ST_LDA + rp16_frag_pos(0, g);
+    int cconv = c_lo;  // the chunk whose S tile is being folded into the running log-sum-exp
+    auto epi_unit = [&](const f32x4& acc, int ft, int rt) {
+      const int col0 = (cconv * 8 + wave) * 32 + 16 * ft + 4 * g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float sv = acc[q] * a.scale;
+        const float d = sv - lm[rt];
+        const float e = __expf(-fabsf(d));
+        ll[rt] = d > 0.0f ? fmaf(ll[rt], e, 1.0f) : ll[rt] + e;
+        lm[rt] = fmaxf(lm[rt], sv);
+        if (col0 + q == tgt[rt]) lt[rt] = sv;
+      }
+    };
+    auto pass = [&](const f32x4* Wc, const f32x4* Wn, f32x4 (&acc)[2][4], const bool epi, const f32x4 (&o)[2][4]) {
+      f32x4 pn[4];
+      pn[0] = *(const f32x4*)(A1);
+      pn[1] = *(const f32x4*)(A1 + 128);
+      pn[2] = *(const f32x4*)(A1 + 16 * ST_LDA);
+      pn[3] = *(const f32x4*)(A1 + 16 * ST_LDA + 128);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const int slot = d & 1;
+        const h8 wh0 = as_h8(rw[slot][0]), wl0 = as_h8(rw[slot][1]), wh1 = as_h8(rw[slot][2]), wl1 = as_h8(rw[slot][3]);
+        if (d + 2 < 8)
+          wfetch(Wc, d + 2, rw[slot]);
+        else
+          wfetch(Wn, d + 2 - 8, rw[slot]);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const h8 p0h = as_h8(pn[0]), p0l = as_h8(pn[1]), p1h = as_h8(pn[2]), p1l = as_h8(pn[3]);
+          if (!(d == 7 && hf == 1)) {
+            const int nd = hf ? d + 1 : d, nrt = hf ? 0 : 2;
+            const float* q = A1 + nrt * 16 * ST_LDA + 8 * nd;
+            pn[0] = *(const f32x4*)(q);
+            pn[1] = *(const f32x4*)(q + 128);
+            pn[2] = *(const f32x4*)(q + 16 * ST_LDA);
+            pn[3] = *(const f32x4*)(q + 16 * ST_LDA + 128);
+          }
+          const int rt = 2 * hf;
+          acc[0][rt] = mfma16x32h(wh0, p0h, acc[0][rt]);
+          acc[1][rt] = mfma16x32h(wh1, p0h, acc[1][rt]);
+          acc[0][rt + 1] = mfma16x32h(wh0, p1h, acc[0][rt + 1]);
+          acc[1][rt + 1] = mfma16x32h(wh1, p1h, acc[1][rt + 1]);
+          acc[0][rt] = mfma16x32h(wl0, p0h, acc[0][rt]);
+          acc[1][rt] = mfma16x32h(wl1, p0h, acc[1][rt]);
+          acc[0][rt + 1] = mfma16x32h(wl0, p1h, acc[0][rt + 1]);
+          acc[1][rt + 1] = mfma16x32h(wl1, p1h, acc[1][rt + 1]);
+          acc[0][rt] = mfma16x32h(wh0, p0l, acc[0][rt]);
+          acc[1][rt] = mfma16x32h(wh1, p0l, acc[1][rt]);
+          acc[0][rt + 1] = mfma16x32h(wh0, p1l, acc[0][rt + 1]);
+          acc[1][rt + 1] = mfma16x32h(wh1, p1l, acc[1][rt + 1]);
+          if (epi && hf == 1) epi_unit(o[d & 1][d >> 1], d & 1, d >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    auto zero = [&](f32x4 (&h)[2][4]) {
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) h[ft][rt] = f32x4{0, 0, 0, 0};
+    };
+    f32x4 ah[2][4];
+    zero(ah);
+    __syncthreads();  // the panel is in P1
+    pass(W1p(c_lo), W1p(min(c_lo + 1, c_hi - 1)), ah, false, ah);
+    for (int c = c_lo; c + 1 < c_hi; ++c) {
+      f32x4 an[2][4];
+      zero(an);
+      cconv = c;
+      pass(W1p(c + 1), W1p(min(c + 2, c_hi - 1)), an, true, ah);  // S of chunk c + 1; chunk c folds into the sums in the MFMAs' shadow
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) ah[ft][rt] = an[ft][rt];
+    }
+    cconv = c_hi - 1;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) epi_unit(ah[ft][rt], ft, rt);
+  }
+  // rows of this lane: 16 rt + r16; the row's four lanes (g = 0 .. 3), then the eight waves through LDS, in index order
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    Lse t{lm[rt], ll[rt]};
+    float tg = lt[rt];
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      Lse u;
+      u.m = __shfl_xor(t.m, o, 64);
+      u.l = __shfl_xor(t.l, o, 64);
+      t = lse_merge(t, u);
+      tg += __shfl_xor(tg, o, 64);
+    }
+    if (g == 0) {
+      float* p = red + (wave * 64 + 16 * rt + r16) * 3;
+      p[0] = t.m;
+      p[1] = t.l;
+      p[2] = tg;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    Lse t{red[tid * 3], red[tid * 3 + 1]};
+    float tg = red[tid * 3 + 2];
+    for (int w = 1; w < 8; ++w) {
+      const float* p = red + (w * 64 + tid) * 3;
+      t = lse_merge(t, Lse{p[0], p[1]});
+      tg += p[2];
+    }
+    a.partial[(size_t)(m0 + tid) * gridDim.y + blockIdx.y] = make_float4(t.m, t.l, tg, 0.0f);
+  }
+}
+int g_sl_fwd16 = 1;  // 0: the 32x32x16 row-panel kernel with the LSE epilogue (tests flip it)
+
 static inline size_t sl_align(size_t v) { return (v + 255) / 256 * 256; }
 
 struct SlWs {
@@ -382,6 +565,19 @@ extern "C" int st_simloss_fwd(const float* ori, const float* like, int Bq, int B
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, (float*)nullptr);
   ST_LAUNCH_CHECK();
   ST_TRY(sl_pack(w.ku, Bk, 256, w.kup, st));
+  if (g_sl_fwd16 && g_sl_format == ST_GEMM_F16X3 && Bq % 64 == 0 && Bk % 256 == 0) {
+    ST_ENSURE_LDS(sl_fwd16_kernel, SLF_LDS);
+    const int panels = Bq / 64, nchunk = Bk / 256;
+    // column splits: about two workgroups per CU, whole chunks, at most SL_SPLITS (the size of `partial`)
+    int splits = std::max(1, std::min(std::min(nchunk, SL_SPLITS), (2 * st_cu_count() + panels / 2) / panels));
+    const int cps = (nchunk + splits - 1) / splits;
+    splits = (nchunk + cps - 1) / cps;
+    SlfArgs f = {w.ou, Bq, w.kup, Bk, cps, 1.0f / tau, row_offset, w.partial};
+    hipLaunchKernelGGL(sl_fwd16_kernel, dim3(panels, splits), dim3(512), SLF_LDS, st, f);
+    hipLaunchKernelGGL(lse_merge_kernel, dim3((Bq + 255) / 256), dim3(256), 0, st, w.partial, splits, Bq, loss, lse);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
   GemmArgs g = {};
   g.fmt = g_sl_format;
   g.X = w.ou; g.n_host = Bq; g.W = w.kup; g.N = Bk; g.scale = 1.0f / tau; g.row_offset = row_offset; g.partial = w.partial;

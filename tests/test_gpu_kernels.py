@@ -726,6 +726,27 @@ def test_every_ab_kernel_form_computes_the_same(dev, ae_sd_torch, gold_notnll):
     assert torch.equal(ids1, ids0) and torch.equal(z1, z0)
 
 
+def test_simloss_forward_forms_agree(dev):
+    """The 16x16x32 forward of the in-batch loss (online log-sum-exp behind the S tiles) against the 32x32x16 row-panel
+    kernel with the LSE epilogue, same inputs: loss and lse of every row within 2e-6 relative (summation orders differ)."""
+    import ctypes as C
+    from style_transfer_amd import _lib, ops
+    g = torch.Generator(device=dev).manual_seed(4)
+    sw = C.c_int.in_dll(_lib.lib(), "g_sl_fwd16")
+    for Bq, Bk, off in ((512, 1024, 256), (8192, 8192, 0), (64, 256, 100)):
+        ori = torch.rand(Bq, 256, device=dev, generator=g) * 10 - 3
+        like = torch.rand(Bk, 256, device=dev, generator=g) * 10 - 3
+        outs = []
+        for v in (1, 0):
+            sw.value = v
+            try:
+                outs.append([t.double().cpu() for t in ops.simloss_fwd(ori, like, 0.1, off)])
+            finally:
+                sw.value = 1
+        for a, b in zip(*outs):
+            assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max()), (Bq, Bk, float((a - b).abs().max()))
+
+
 def test_simloss_chunked_backward_form_equals_fused(dev):
     """ST_AB_SIMLOSS_CHUNKED: the round-2 backward (dS through HBM) against the fused kernel, same inputs"""
     import ctypes as C
