@@ -586,8 +586,8 @@ def main(argv=None):
                                           "row and layer; the first-layer launches compute their residual from the 9.5 MB embedding "
                                           "table, which is counted as cache-resident here but mostly misses the 4 MB of L2 per XCD "
                                           "(the measured traffic did not change when those launches stopped reading x): that and "
-                                          "weight fragments that miss L2 are the excess; at 8 TB/s the traffic is 0.19 ms of a 1.04 ms "
-                                          "launch") if split else None,
+                                          "weight fragments that miss L2 are the excess; at 8 TB/s the traffic is %.2f ms of a %.2f ms "
+                                          "launch" % (traffic / 8e9, gen_ms.value / max(1, gen_n.value))) if (split and traffic) else None,
                              "mfma_flops_per_algorithmic_flop": 3 if split else 1,
                              "mfma_issue_frac": achieved * (3 if split else 1) / peak,
                              "achieved_over_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
