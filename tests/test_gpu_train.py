@@ -310,13 +310,14 @@ def test_ae_train_step_with_dropout_matches_the_oracle(ae_sd_torch, ae_sd):
     assert abs(keep_mask(seed, 11, np.arange(200000), 0.1).mean() - 0.9) < 5e-3
 
 
-# (switch, value, tolerance on every tensor's gradient relative to its norm).  Forms that re-order sums: 2e-5.  Forms that
-# change the FORWARD products' rounding (split f16 <-> exact f32, ~ 3e-7 relative on activations): 2e-2, because the step is
+# (switch, value, tolerance on every tensor's gradient relative to its norm).  Forms that re-order BACKWARD sums: 2e-5.  Forms
+# that change the rounding of FORWARD values (split f16 <-> exact f32, ~ 3e-7 relative on activations; the attention kernels'
+# summation order, ~ 1e-7: measured 1.2e-5 here, but nothing pins it there): 2e-2, because the step is
 # not continuous at that scale -- a pre-activation within 3e-7 of zero flips its ReLU, and one flip moves the first FFN's
 # weight gradient by ~ 1e-3 of its norm; the EXACT-f32 step answers a 3e-7 perturbation of its parameters with the same
 # 5e-3 jumps in the same tensors (tools/ae_fwd_format_probe2.py); on the reference's golden batch the two formats agree
 # to 2e-6 (tools/ae_fwd_format_probe.py) and both meet the reference's gradients to the same 1e-4.
-AE_FORMS = [("g_ae_att16", 0, 2e-5), ("g_ae_dw", 1, 2e-5), ("g_ae_dw", 0, 2e-5), ("g_ae_fwd_h", 0, 2e-2), ("g_ae_force_redo", 1, 2e-2),
+AE_FORMS = [("g_ae_att16", 0, 2e-2), ("g_ae_dw", 1, 2e-5), ("g_ae_dw", 0, 2e-5), ("g_ae_fwd_h", 0, 2e-2), ("g_ae_force_redo", 1, 2e-2),
             ("g_ae_rp", 0, 2e-2)]
 
 
