@@ -312,7 +312,7 @@ def test_ae_train_step_with_dropout_matches_the_oracle(ae_sd_torch, ae_sd):
 
 # (switch, value, tolerance on every tensor's gradient relative to its norm).  Forms that re-order BACKWARD sums: 2e-5.  Forms
 # that change the rounding of FORWARD values (split f16 <-> exact f32, ~ 3e-7 relative on activations; the attention kernels'
-# summation order, ~ 1e-7: measured 1.2e-5 here, but nothing pins it there): 2e-2, because the step is
+# summation order, ~ 1e-7: below 2e-5 on this batch, but nothing pins it there): 2e-2, because the step is
 # not continuous at that scale -- a pre-activation within 3e-7 of zero flips its ReLU, and one flip moves the first FFN's
 # weight gradient by ~ 1e-3 of its norm; the EXACT-f32 step answers a 3e-7 perturbation of its parameters with the same
 # 5e-3 jumps in the same tensors (tools/ae_fwd_format_probe2.py); on the reference's golden batch the two formats agree
