@@ -79,6 +79,114 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __res
   if (lane == 0) rowscale[r] = sc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small blocks (Bq, Bk <= SL_SMALL: the reference's training batch of 128, the goldens' 32): one kernel per pass, wave per
+// row, plain f32 FMAs -- a 128 x 128 block is 4 MFLOP, and the GEMM path above spends 5 launches forward and 9 backward
+// (~ 11 us each) on it.  Same formulas: rows normalised to unit length, s = u . v / tau, online log-sum-exp; backward
+// d u_i = sum_j g_i (softmax_ij - [j = target]) / tau * v_j through the normalisation's Jacobian, and the same with the
+// roles swapped for the keys (d_like is ADDED to, d_ori written, as in the GEMM path).
+// ------------------------------------------------------------------------------------------------
+#define SL_SMALL 128  /* 256: the wave-per-row loops get long, the AE step at B = 256 measured 8.4 ms against 7.4 on the GEMM path */
+__device__ __forceinline__ f32x4 sl_unit(const float* __restrict__ x, int r, int lane, float& nrm) {
+  f32x4 v = *(const f32x4*)(x + (size_t)r * 256 + lane * 4);
+  nrm = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w)), 1e-8f);
+  return v / nrm;
+}
+__device__ __forceinline__ float sl_dot(const f32x4& a, const f32x4& b) { return wave_sum(a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w); }
+__global__ __launch_bounds__(256) void sl_small_fwd_kernel(const float* __restrict__ ori, const float* __restrict__ like, int Bq, int Bk,
+                                                           float scale, int row_offset, float* __restrict__ loss, float* __restrict__ lse) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= Bq) return;
+  const int lane = threadIdx.x & 63;
+  float nn;
+  const f32x4 u = sl_unit(ori, i, lane, nn);
+  Lse t = {-INFINITY, 0.0f};
+  float tg = 0.0f;
+  auto fold = [&](int j, float sv) {
+    const float d = sv - t.m;
+    const float e = expf(-fabsf(d));
+    t.l = d > 0.0f ? fmaf(t.l, e, 1.0f) : t.l + e;
+    t.m = fmaxf(t.m, sv);
+    if (j == row_offset + i) tg = sv;
+  };
+  int j = 0;
+  for (; j + 1 < Bk; j += 2) {  // two keys at a time: two independent reduction chains in flight
+    float n0, n1;
+    const f32x4 v0 = sl_unit(like, j, lane, n0), v1 = sl_unit(like, j + 1, lane, n1);
+    const float s0 = sl_dot(u, v0) * scale, s1 = sl_dot(u, v1) * scale;
+    fold(j, s0);
+    fold(j + 1, s1);
+  }
+  if (j < Bk) {
+    float n0;
+    fold(j, sl_dot(u, sl_unit(like, j, lane, n0)) * scale);
+  }
+  if (lane == 0) {
+    const float l = t.m + logf(t.l);
+    lse[i] = l;
+    loss[i] = l - tg;
+  }
+}
+// blocks [0, ceil(Bq / 4)): wave per query -> d_ori;  the rest: wave per key -> d_like +=
+__global__ __launch_bounds__(256) void sl_small_bwd_kernel(const float* __restrict__ ori, const float* __restrict__ like, int Bq, int Bk,
+                                                           float scale, int row_offset, const float* __restrict__ lse,
+                                                           const float* __restrict__ g, float* __restrict__ d_ori, float* __restrict__ d_like) {
+  const int qblocks = (Bq + 3) / 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  f32x4 acc = {0, 0, 0, 0};
+  if ((int)blockIdx.x < qblocks) {
+    const int i = blockIdx.x * 4 + w;
+    if (i >= Bq) return;
+    float nn;
+    const f32x4 u = sl_unit(ori, i, lane, nn);
+    const float li = lse[i], gi = g[i] * scale;
+    auto term = [&](int j, const f32x4& v, float dot) {
+      const float p = expf(dot * scale - li) - (j == row_offset + i ? 1.0f : 0.0f);
+      acc += (gi * p) * v;
+    };
+    int j = 0;
+    for (; j + 1 < Bk; j += 2) {
+      float n0, n1;
+      const f32x4 v0 = sl_unit(like, j, lane, n0), v1 = sl_unit(like, j + 1, lane, n1);
+      const float d0 = sl_dot(u, v0), d1 = sl_dot(u, v1);
+      term(j, v0, d0);
+      term(j + 1, v1, d1);
+    }
+    if (j < Bk) {
+      float n0;
+      const f32x4 v0 = sl_unit(like, j, lane, n0);
+      term(j, v0, sl_dot(u, v0));
+    }
+    const f32x4 o = (acc - sl_dot(acc, u) * u) / nn;
+    *(f32x4*)(d_ori + (size_t)i * 256 + lane * 4) = o;
+  } else {
+    const int j = (blockIdx.x - qblocks) * 4 + w;
+    if (j >= Bk) return;
+    float nk;
+    const f32x4 v = sl_unit(like, j, lane, nk);
+    auto term = [&](int i, const f32x4& u, float dot) {
+      const float p = expf(dot * scale - lse[i]) - (j == row_offset + i ? 1.0f : 0.0f);
+      acc += (g[i] * scale * p) * u;
+    };
+    int i = 0;
+    for (; i + 1 < Bq; i += 2) {
+      float n0, n1;
+      const f32x4 u0 = sl_unit(ori, i, lane, n0), u1 = sl_unit(ori, i + 1, lane, n1);
+      const float d0 = sl_dot(u0, v), d1 = sl_dot(u1, v);
+      term(i, u0, d0);
+      term(i + 1, u1, d1);
+    }
+    if (i < Bq) {
+      float n0;
+      const f32x4 u0 = sl_unit(ori, i, lane, n0);
+      term(i, u0, sl_dot(u0, v));
+    }
+    float* dst = d_like + (size_t)j * 256 + lane * 4;
+    *(f32x4*)dst = *(const f32x4*)dst + (acc - sl_dot(acc, v) * v) / nk;
+  }
+}
+int g_sl_small = 1;  // 0: small blocks through the GEMM path as well (tests flip it)
+
 // Operand format of the similarity GEMMs (ST_GEMM_*).  F16X3 (default): unit rows lie in [-1, 1] and dS in [-1, 1], the
 // ideal domain of the hi + lo split (f32-grade: ~2^-22 per term), and every product of the block runs on the f16 MFMA.
 static int g_sl_format = ST_GEMM_F16X3;
@@ -560,6 +668,11 @@ extern "C" int st_simloss_fwd(const float* ori, const float* like, int Bq, int B
   ST_TRY(sl_check(ori, like, Bq, Bk, tau, row_offset, scratch, scratch_bytes));
   ST_CHECK_ARG(loss && lse, "NULL output");
   hipStream_t st = (hipStream_t)stream;
+  if (g_sl_small && Bq <= SL_SMALL && Bk <= SL_SMALL) {
+    hipLaunchKernelGGL(sl_small_fwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, like, Bq, Bk, 1.0f / tau, row_offset, loss, lse);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
   SlWs w = sl_carve(Bq, Bk, (char*)scratch);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, (float*)nullptr);
@@ -594,6 +707,12 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
   ST_CHECK_ARG(lse && g && d_ori && d_like, "NULL buffer");
   ST_CHECK_ARG(Bq % 32 == 0 && Bk % 32 == 0, "backward needs Bq and Bk to be multiples of 32 (Bq=%d Bk=%d)", Bq, Bk);
   hipStream_t st = (hipStream_t)stream;
+  if (g_sl_small && Bq <= SL_SMALL && Bk <= SL_SMALL) {
+    hipLaunchKernelGGL(sl_small_bwd_kernel, dim3((Bq + 3) / 4 + (Bk + 3) / 4), dim3(256), 0, st, ori, like, Bq, Bk, 1.0f / tau, row_offset,
+                       lse, g, d_ori, d_like);
+    ST_LAUNCH_CHECK();
+    return ST_OK;
+  }
   SlWs w = sl_carve(Bq, Bk, (char*)scratch);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, Bq, w.ou, w.on, (float*)nullptr);
   hipLaunchKernelGGL(unit_rows_kernel, dim3((Bk + 3) / 4), dim3(256), 0, st, like, Bk, w.ku, w.kn, w.kut);

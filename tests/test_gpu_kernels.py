@@ -747,6 +747,31 @@ def test_simloss_forward_forms_agree(dev):
             assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max()), (Bq, Bk, float((a - b).abs().max()))
 
 
+def test_simloss_small_block_kernels_agree_with_the_gemm_path(dev):
+    """Blocks of at most 128 x 128 run in one plain-f32 kernel per pass; the GEMM path (either operand format) must give
+    the same loss, lse and gradients (1e-5 of each tensor's largest entry; d_like is added to what the buffer holds)."""
+    import ctypes as C
+    from style_transfer_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator(device=dev).manual_seed(6)
+    sw = C.c_int.in_dll(L, "g_sl_small")
+    for Bq, Bk, off in ((128, 128, 0), (32, 32, 0), (64, 128, 64), (32, 96, 10)):
+        ori = torch.rand(Bq, 256, device=dev, generator=g) * 10 - 3
+        like = torch.rand(Bk, 256, device=dev, generator=g) * 10 - 3
+        gw = torch.rand(Bq, device=dev, generator=g) / Bq
+        outs = []
+        for v in (1, 0):
+            sw.value = v
+            try:
+                loss, lse = ops.simloss_fwd(ori, like, 0.1, off)
+                d_ori, d_like = ops.simloss_bwd(ori, like, lse, gw, 0.1, off)
+                outs.append([t.double().cpu() for t in (loss, lse, d_ori, d_like)])
+            finally:
+                sw.value = 1
+        for name, a, b in zip(("loss", "lse", "d_ori", "d_like"), *outs):
+            assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max()), (Bq, Bk, name, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def test_simloss_chunked_backward_form_equals_fused(dev):
     """ST_AB_SIMLOSS_CHUNKED: the round-2 backward (dS through HBM) against the fused kernel, same inputs"""
     import ctypes as C
