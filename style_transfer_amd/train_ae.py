@@ -138,11 +138,11 @@ class AETrainer:
         return s
 
     # -- data: one batch in the reference's roles --------------------------------------------------
-    def pack(self, origin, views, bos=2, eos=3, unk=1, max_seq_length=60):
+    @staticmethod
+    def pack_lists(origin, views, vocab, bos=2, eos=3, unk=1, max_seq_length=60):
         """origin: B id lists; views: K lists of B id lists (view-major, like_tensor_src [like_num, batch, seq]).
-        -> device int32 arrays of the length-packed encoder batch (origins | views | origins) and decoder batch."""
-        V = self.vocab
-        clip = lambda s: [t if t < V else unk for t in s[: max_seq_length - 1]]
+        -> the int32 numpy arrays of the length-packed encoder batch (origins | views | origins) and decoder batch"""
+        clip = lambda s: [t if t < vocab else unk for t in s[: max_seq_length - 1]]
         origin = [clip(s) for s in origin]
         enc_sents = origin + [clip(s) for view in views for s in view] + origin
         tok, pos, off, mx = pack_sentences(enc_sents)
@@ -152,13 +152,70 @@ class AETrainer:
         dtok, dpos, doff, dmx = pack_sentences(dec_in)
         dtgt = np.fromiter((t for s in dec_tgt for t in s), np.int32, dtok.size)
         assert dmx <= 64
+        return (tok, pos, off), (dtok, dpos, dtgt, doff), enc_sents, origin
+
+    def pack(self, origin, views, bos=2, eos=3, unk=1, max_seq_length=60):
+        """pack_lists -> device int32 arrays"""
+        enc, dec, enc_sents, origin = self.pack_lists(origin, views, self.vocab, bos, eos, unk, max_seq_length)
         dev = self.device
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
-        return dict(B=len(origin), n_sent=len(enc_sents), enc=(t(tok), t(pos), t(off)), dec=(t(dtok), t(dpos), t(dtgt), t(doff)),
+        return dict(B=len(origin), n_sent=len(enc_sents), enc=tuple(t(a) for a in enc), dec=tuple(t(a) for a in dec),
                     enc_sents=enc_sents, origin=origin)
 
-    def loss_and_grads(self, batch, seed=None):
-        """-> (reconstruction loss, constraint loss) as floats; self.grads holds d(bata * constraint + rec) / d params"""
+    @staticmethod
+    def pack_arrays(origin_r, views_r, vocab, bos=2, eos=3, unk=1, max_seq_length=60):
+        """pack() on flat arrays, without a per-sentence Python loop (the epoch loop's form: at the reference's batch of
+        128 records the list version costs ~ 4 ms of host time per 5 ms step).  origin_r: Ragged of B sentences; views_r:
+        Ragged of K * B sentences, view-major.  -> (enc tokens, positions, offsets), (dec tokens, positions, targets,
+        offsets), n_sent: int32 numpy arrays equal to what pack() sends to the device."""
+        def clip(r):
+            lens = r.lens
+            tok = np.where(r.tokens < vocab, r.tokens, unk).astype(np.int32)
+            limit = max_seq_length - 1
+            if lens.size and int(lens.max()) > limit:
+                pos = np.arange(tok.size, dtype=np.int64) - np.repeat(r.off[:-1], lens)
+                tok = tok[pos < limit]
+                lens = np.minimum(lens, limit)
+            return Ragged.from_lengths(tok, lens)
+        o = clip(origin_r)
+        enc = Ragged.concat([o, clip(views_r), o])
+        tok, pos, off, mx = pack_sentences(enc)
+        assert mx <= 64 and tok.size == enc.tokens.size, "training sentences: <= 64 tokens, no PAD ids inside"
+        B, lens = len(o), o.lens
+        doff = np.zeros(B + 1, np.int64)
+        np.cumsum(lens + 1, out=doff[1:])
+        n = int(doff[-1])
+        first = np.zeros(n, bool)
+        first[doff[:-1]] = True
+        last = np.zeros(n, bool)
+        last[doff[1:] - 1] = True
+        dtok = np.empty(n, np.int32)
+        dtok[first] = bos
+        dtok[~first] = o.tokens
+        dtgt = np.empty(n, np.int32)
+        dtgt[last] = eos
+        dtgt[~last] = o.tokens
+        dpos = (np.arange(n, dtype=np.int64) - np.repeat(doff[:-1], lens + 1)).astype(np.int32)
+        assert int(lens.max()) + 1 <= 64
+        return (tok, pos, off), (dtok, dpos, dtgt, doff.astype(np.int32)), len(enc)
+
+    def pack_ragged(self, origin_r, views_r):
+        """pack() for the epoch loop: Ragged arrays in, pinned staging, asynchronous copies (the buffers stay alive in the
+        returned dict until the step that reads them has been queued)"""
+        enc, dec, n_sent = self.pack_arrays(origin_r, views_r, self.vocab)
+        host = []
+
+        def t(a):
+            src = torch.from_numpy(np.ascontiguousarray(a, np.int32))
+            pin = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            pin.copy_(src)
+            host.append(pin)
+            return pin.to(self.device, non_blocking=True)
+        return dict(B=len(origin_r), n_sent=n_sent, enc=tuple(t(a) for a in enc), dec=tuple(t(a) for a in dec), _host=host)
+
+    def loss_and_grads(self, batch, seed=None, fetch=True):
+        """-> (reconstruction loss, constraint loss) as floats; self.grads holds d(bata * constraint + rec) / d params.
+        fetch=False: no host synchronisation, the two losses stay in self.losses (device) and None is returned"""
         c = self.cfg
         et, ep, eo = batch["enc"]
         dt, dp, dy, do = batch["dec"]
@@ -174,6 +231,8 @@ class AETrainer:
                                  float(c.bata), float(c.tau), float(c.smoothing), float(c.dropout), int(seed) & (2 ** 64 - 1),
                                  self.losses.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                                  torch.cuda.current_stream().cuda_stream), "st_ae_train_step")
+        if not fetch:
+            return None
         rec, con = self.losses.tolist()
         return rec, con
 
@@ -243,17 +302,25 @@ def train_ae_model_constraint(trainer: AETrainer, data, batch_size=128, epochs=1
     hist = []
     for epoch in range(epochs):
         log(headline("Start Running Epoch {}".format(epoch)))
-        rec_sum = con_sum = 0.0
+        # the loss sums live on the device and are read when a line is logged (every 200 batches, as the reference prints)
+        # and at the end of the epoch: no host synchronisation per step, so packing the next batch (flat arrays, no
+        # per-sentence Python) and queueing its ~ 400 launches overlap the current step on the GPU
+        sums = torch.zeros(2, dtype=torch.float64, device=trainer.device)
         batches = epoch_order(len(data), batch_size)
+        K = data.n_pos
+        keep = None
         for it, recs in enumerate(batches):
-            origin = [data.origin[i] for i in recs]
-            views = [[data.like[i][j] for i in recs] for j in range(data.n_pos)]
-            rec, con = trainer.loss_and_grads(trainer.pack(origin, views))
+            idx = np.asarray(recs, np.int64)
+            views = data.like_r.take((idx[None, :] * K + np.arange(K, dtype=np.int64)[:, None]).reshape(-1))   # view-major
+            batch = trainer.pack_ragged(data.origin_r.take(idx), views)
+            trainer.loss_and_grads(batch, fetch=False)
             trainer.step()
-            rec_sum += rec
-            con_sum += con
+            sums += trainer.losses
+            keep = (batch, keep[0] if keep else None)     # the pinned staging of the last two batches stays alive
             if it % 200 == 0:
+                rec_sum, con_sum = sums.tolist()
                 log("epoch {}, batch {}, rec loss={}, constraint loss={}".format(epoch, it, rec_sum / (it + 1), con_sum / (it + 1)))
+        rec_sum, con_sum = sums.tolist()
         hist.append((rec_sum / max(1, len(batches)), con_sum / max(1, len(batches))))
         if save_path is not None:
             torch.save(trainer.state_dict(), os.path.join(save_path, "constraint_ae_model{:d}_params.pkl".format(epoch)))

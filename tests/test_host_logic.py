@@ -458,3 +458,21 @@ def test_parallel_log_formatter_equals_the_single_block(id_to_word):
     sub = rec.span(100, 250)
     assert len(sub) == 150 and int(sub.changed.sum()) == sub.rows.shape[0]
     assert format_attack_block(vocab, full.span(100, 250), sub, 107).tobytes() in one
+
+
+
+def test_ae_training_batches_pack_the_same_from_lists_and_from_flat_arrays():
+    """AETrainer.pack_arrays (the epoch loop's vectorised form) against pack_lists (the per-sentence form the golden tests
+    use): the same encoder and decoder arrays, including sentences longer than max_seq_length - 1 and ids outside the vocabulary."""
+    from style_transfer_amd.data import Ragged
+    from style_transfer_amd.train_ae import AETrainer
+    rng = np.random.default_rng(8)
+    V, B, K = 500, 32, 10
+    sent = lambda: [int(t) for t in rng.integers(4, V + 40, int(rng.integers(1, 70) if rng.random() < 0.1 else rng.integers(1, 16)))]
+    origin = [sent() for _ in range(B)]
+    views = [[sent() for _ in range(B)] for _ in range(K)]
+    enc_l, dec_l, enc_sents, _ = AETrainer.pack_lists(origin, views, V)
+    enc_a, dec_a, n_sent = AETrainer.pack_arrays(Ragged.from_lists(origin), Ragged.from_lists([s for v in views for s in v]), V)
+    assert n_sent == len(enc_sents) == (K + 2) * B
+    for a, b in zip(enc_l + dec_l, enc_a + dec_a):
+        assert np.array_equal(np.asarray(a, np.int64), np.asarray(b, np.int64))
