@@ -351,6 +351,9 @@ __global__ __launch_bounds__(256, 4) void ae_dw_kernel(DwArgs a) {
 // operand pairs from there (ds_read_b64, lane l of a half = outputs 2 l, 2 l + 1: 256 contiguous bytes per half-wave,
 // conflict-free without padding).  One barrier per chunk.
 #define DWL_ROWS 16
+#ifndef DW_MIN_SLICE_ROWS
+#define DW_MIN_SLICE_ROWS 64  /* at 13 k rows (B = 128): 64 -> 5.39 ms per step, 128 -> 5.39, 256 -> 5.59, 512 -> 6.19: workgroups count for more than the slab's bytes */
+#endif
 __global__ __launch_bounds__(256, 4) void ae_dw_lds_kernel(DwArgs a) {
   __shared__ __align__(16) float sA[2][DWL_ROWS][128], sB[2][DWL_ROWS][128];
   const int nb = gridDim.x;  // a multiple of 8
@@ -1313,7 +1316,7 @@ struct Ctx {
     a.A = dY; a.B = X; a.M = M; a.N = N; a.R = R; a.lda = M; a.ldb = N;
     a.tiles_n = (N + 127) / 128;
     a.tiles = a.tiles_n * ((M + 127) / 128);
-    int nz = std::max(1, std::min((1024 + a.tiles - 1) / a.tiles, R / 64));  // ~ 4 workgroups per CU (4 waves per SIMD at 120 registers)
+    int nz = std::max(1, std::min((1024 + a.tiles - 1) / a.tiles, R / DW_MIN_SLICE_ROWS));  // ~ 4 workgroups per CU (4 waves per SIMD at 120 registers)
     while (nz > 1 && (size_t)nz * ((size_t)M * N + M) > slab_floats) --nz;
     a.per = ((R + nz - 1) / nz + 2 * DW_U - 1) / (2 * DW_U) * (2 * DW_U);
     a.nz = (R + a.per - 1) / a.per;
