@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ em
 // block = one live row, wave = head, lane j = key position j (pos+1 <= 64 keys), then lane d = out dim.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
-                                                        const float* __restrict__ vbase, long kv_stride,
+                                                        const float* __restrict__ vbase, long kv_stride, long pos_stride,
                                                         const int* __restrict__ idx, const int* __restrict__ n_dev,
                                                         int pos, float* __restrict__ out) {
   __shared__ __align__(16) float qs[256];
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
   const float* V = vbase + s * kv_stride + h * 64;
   float sc = -INFINITY;
   if (lane <= pos) {
-    const float* kr = K + (size_t)lane * 256;
+    const float* kr = K + (size_t)lane * pos_stride;
     float acc = 0.0f;
 #pragma unroll
     for (int d = 0; d < 64; d += 4) {
@@ -173,14 +173,14 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
   float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;   // four independent chains keep four V loads in flight
   int j = 0;
   for (; j + 3 <= pos; j += 4) {
-    const float v0 = V[(size_t)j * 256 + lane], v1 = V[(size_t)(j + 1) * 256 + lane];
-    const float v2 = V[(size_t)(j + 2) * 256 + lane], v3 = V[(size_t)(j + 3) * 256 + lane];
+    const float v0 = V[(size_t)j * pos_stride + lane], v1 = V[(size_t)(j + 1) * pos_stride + lane];
+    const float v2 = V[(size_t)(j + 2) * pos_stride + lane], v3 = V[(size_t)(j + 3) * pos_stride + lane];
     o0 = fmaf(__shfl(p, j, 64), v0, o0);
     o1 = fmaf(__shfl(p, j + 1, 64), v1, o1);
     o2 = fmaf(__shfl(p, j + 2, 64), v2, o2);
     o3 = fmaf(__shfl(p, j + 3, 64), v3, o3);
   }
-  for (; j <= pos; ++j) o0 = fmaf(__shfl(p, j, 64), V[(size_t)j * 256 + lane], o0);
+  for (; j <= pos; ++j) o0 = fmaf(__shfl(p, j, 64), V[(size_t)j * pos_stride + lane], o0);
   out[(size_t)r * 256 + h * 64 + lane] = (o0 + o1) + (o2 + o3);
 }
 
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
 // FAST (f16x3 format): softmax exponential through v_exp_f32 (as in the encoder's attention, st_encode.hip).
 template <bool FAST>
 __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
-                                                          const float* __restrict__ vbase, long kv_stride,
+                                                          const float* __restrict__ vbase, long kv_stride, long pos_stride,
                                                           const int* __restrict__ idx, const int* __restrict__ n_dev,
                                                           int pos, float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < 16; ++j)
     if (j <= pos) {  // uniform
-      kr[j] = *(const f32x4*)(K + (size_t)j * 256);
-      vr[j] = *(const f32x4*)(V + (size_t)j * 256);
+      kr[j] = *(const f32x4*)(K + (size_t)j * pos_stride);
+      vr[j] = *(const f32x4*)(V + (size_t)j * pos_stride);
     }
   float sc[16];
   float m = -INFINITY;
@@ -769,7 +769,14 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     return ST_ENOMEM;
   }
   const int early = (options & ST_DEC_EARLY_EXIT) ? 1 : 0;
-  const long kv_stride = (long)(kv_layers > 0 ? kv_layers : 1) * 2 * T * 256;
+  // K / V cache layout.  Job-major (default): [job][layer][k | v][position][256]: a decode step writes 1 KB per job, layer and
+  // side and reads (pos + 1) KB, at a stride of ~ 120 KB across up to 140 GB.  Position-major (ST_AB_KV_POS_MAJOR):
+  // [layer][k | v][position][job][256]: a step writes one contiguous slab of job rows and reads pos + 1 such slabs front to
+  // back.  Built to test whether page (TLB) locality holds the attention and QKV kernels back: it does not -- same-box
+  // 184.9 / 185.5 k against 184.8 / 185.5 k sentences/s, identical results (profiles/r03_round_end_ab.txt).
+  const bool kv_pm = rp_kv_pos_major != 0;
+  const long kv_stride = kv_pm ? 256 : (long)(kv_layers > 0 ? kv_layers : 1) * 2 * T * 256;   // floats between two jobs
+  const long kv_pos_stride = kv_pm ? (long)B * 256 : 256;                                       // floats between two positions
   unsigned long long* work = nullptr;
   ST_TRY(st_work_counters_ptr(&work));
 
@@ -802,7 +809,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
   // set (same-box A/B, profiles/r03_dec_fused_negative.txt: identical results, 130 k against 145 k sentences/s).  Its
   // attention phase has 8 waves x 1-4 rows in flight per CU and each wave walks its 16 rows in sequential HBM round trips;
   // attn_step16_kernel keeps 12 independent rows per CU in flight all the time.
-  const bool fuse_qkv_attn = w->gemm_format == ST_GEMM_F16X3 && rp_dec_fused && kv_stride % 4 == 0 && ((size_t)ws.kv & 15) == 0;
+  const bool fuse_qkv_attn = w->gemm_format == ST_GEMM_F16X3 && rp_dec_fused && !kv_pm && kv_stride % 4 == 0 && ((size_t)ws.kv & 15) == 0;
   const int fuse_min_rows = 1;
   int n_bound = B;
   int cur = 0;
@@ -823,8 +830,9 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
     for (int l = 0; l < L; ++l) {
       const StDecLayer& y = w->layer[l];
       const int lk = l - kv_first;   // this layer's place in the K / V cache (-1: the table layer keeps none)
-      float* kb = lk >= 0 ? ws.kv + (size_t)(lk * 2 + 0) * T * 256 : nullptr;
-      float* vb = lk >= 0 ? ws.kv + (size_t)(lk * 2 + 1) * T * 256 : nullptr;
+      const size_t side = (size_t)T * 256 * (kv_pm ? (size_t)B : 1);   // floats of one layer's K (or V) block
+      float* kb = lk >= 0 ? ws.kv + (size_t)(lk * 2 + 0) * side : nullptr;
+      float* vb = lk >= 0 ? ws.kv + (size_t)(lk * 2 + 1) * side : nullptr;
       if (l == 0 && use_tab) {
         // first layer: q | k | v of (token, position) from the table; no projection, no K / V cache rows
         if (pos < 16)
@@ -839,7 +847,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       g.fmt = w->gemm_format; g.range_flag = ws.cnt + 3;
       g.X = ws.x; g.n_dev = n_dev; g.n_host = n_bound; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b;
       g.W = y.wqkv; g.bias = y.bqkv; g.N = 768; g.idx = idx; g.q = ws.q;
-      g.kbase = kb + (size_t)pos * 256; g.vbase = vb + (size_t)pos * 256; g.kv_stride = kv_stride;
+      g.kbase = kb + (size_t)pos * kv_pos_stride; g.vbase = vb + (size_t)pos * kv_pos_stride; g.kv_stride = kv_stride;
       const int qsplits = rp_splits(n_bound, 768, n_bound <= 2048 ? 8 : 3, rp_nw(w->gemm_format, 8));
       if (fuse_qkv_attn && pos < 16 && n_bound >= fuse_min_rows) {
         g.kbase = kb; g.vbase = vb; g.pos = pos; g.out = ws.att;   // (bases without the pos offset)
@@ -850,13 +858,13 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       else
         ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, qsplits, st)));
       if (pos < 16 && w->gemm_format == ST_GEMM_F16X3)
-        hipLaunchKernelGGL(attn_step16_kernel<true>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
+        hipLaunchKernelGGL(attn_step16_kernel<true>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx,
                            n_dev, pos, ws.att);
       else if (pos < 16)
-        hipLaunchKernelGGL(attn_step16_kernel<false>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx,
+        hipLaunchKernelGGL(attn_step16_kernel<false>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx,
                            n_dev, pos, ws.att);
       else
-        hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, idx, n_dev, pos,
+        hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx, n_dev, pos,
                            ws.att);
       ST_LAUNCH_CHECK();
       }

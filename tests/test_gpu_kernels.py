@@ -684,7 +684,7 @@ def test_first_encoder_layer_table_gives_the_same_latents(dev, ae_sd_torch):
 # (st_rowpanel.h, st_simloss.hip) that the environment sets once per process; the test flips them directly
 AB_SWITCHES = [("rp_tail_shape16", 0), ("rp_tail_persistent", 0), ("rp_lin_shape16", 0), ("rp_screen_shape16", 0),
                ("rp_screen_paired", 0), ("rp_screen_maxnorm", 1), ("rp_argmax_shape16", 0), ("rp_enc_unfused", 1),
-               ("rp_dec_fused", 1), ("rp_tail_min_rows", 4096), ("rp_no_emb_in_tail", 1)]
+               ("rp_dec_fused", 1), ("rp_tail_min_rows", 4096), ("rp_no_emb_in_tail", 1), ("rp_kv_pos_major", 1)]
 
 
 def test_every_ab_kernel_form_computes_the_same(dev, ae_sd_torch, gold_notnll):
