@@ -191,11 +191,15 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* __restrict_
 // of a head ends up with all of that head's scores and the softmax needs no further lane traffic; the PV sum
 // is lane-local.  All 2(pos+1) loads of a row are independent and issued up front.
 // FAST (f16x3 format): softmax exponential through v_exp_f32 (as in the encoder's attention, st_encode.hip).
-template <bool FAST>
+// NK = pos + 1, the number of keys, is a TEMPLATE parameter (the step is the same for every row of a launch): with a
+// run-time pos the unrolled 16-key body kept its softmax and P.V parts for all 16 keys behind selects (96 v_cndmask,
+// 16 v_exp per row whatever pos was) and the kernel's floor -- its time with K / V served from L2 -- was ~ 0.6 of its
+// time: VALU issue, not HBM.  Same operations in the same order on the keys that exist: identical results.
+template <bool FAST, int NK>
 __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restrict__ q, const float* __restrict__ kbase,
                                                           const float* __restrict__ vbase, long kv_stride, long pos_stride,
                                                           const int* __restrict__ idx, const int* __restrict__ n_dev,
-                                                          int pos, float* __restrict__ out) {
+                                                          float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= *n_dev) return;
@@ -203,37 +207,45 @@ __global__ __launch_bounds__(256) void attn_step16_kernel(const float* __restric
   const float* K = kbase + s * kv_stride + lane * 4;
   const float* V = vbase + s * kv_stride + lane * 4;
   const f32x4 qv = *(const f32x4*)(q + (size_t)r * 256 + lane * 4);
-  f32x4 kr[16], vr[16];
+  f32x4 kr[NK], vr[NK];
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j <= pos) {  // uniform
-      kr[j] = *(const f32x4*)(K + (size_t)j * pos_stride);
-      vr[j] = *(const f32x4*)(V + (size_t)j * pos_stride);
-    }
-  float sc[16];
+  for (int j = 0; j < NK; ++j) {
+    kr[j] = *(const f32x4*)(K + (size_t)j * pos_stride);
+    vr[j] = *(const f32x4*)(V + (size_t)j * pos_stride);
+  }
+  float sc[NK];
   float m = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    sc[j] = -INFINITY;
-    if (j <= pos) {
-      const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
-      sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
-      m = fmaxf(m, sc[j]);
-    }
+  for (int j = 0; j < NK; ++j) {
+    const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
+    sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
+    m = fmaxf(m, sc[j]);
   }
   float sum = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j <= pos) {
-      sc[j] = FAST ? __expf(sc[j] - m) : expf(sc[j] - m);
-      sum += sc[j];
-    }
+  for (int j = 0; j < NK; ++j) {
+    sc[j] = FAST ? __expf(sc[j] - m) : expf(sc[j] - m);
+    sum += sc[j];
+  }
   const float inv = 1.0f / sum;
   f32x4 o4 = {0, 0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j <= pos) o4 += (sc[j] * inv) * vr[j];
+  for (int j = 0; j < NK; ++j) o4 += (sc[j] * inv) * vr[j];
   *(f32x4*)(out + (size_t)r * 256 + lane * 4) = o4;
+}
+#define ST_NK_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+template <bool FAST>
+static void launch_attn_step16(int nk, int n_bound, hipStream_t st, const float* q, const float* kb, const float* vb, long kv_stride,
+                               long pos_stride, const int* idx, const int* n_dev, float* out) {
+  switch (nk) {
+#define ST_NK_CASE(N)                                                                                                       \
+  case N:                                                                                                                   \
+    hipLaunchKernelGGL((attn_step16_kernel<FAST, N>), dim3((n_bound + 3) / 4), dim3(256), 0, st, q, kb, vb, kv_stride, pos_stride, \
+                       idx, n_dev, out);                                                                                    \
+    break;
+    ST_NK_CASES(ST_NK_CASE)
+#undef ST_NK_CASE
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,11 +266,12 @@ __global__ __launch_bounds__(256) void l0_embed_kernel(const float* __restrict__
   *(f32x4*)(x + (size_t)r * 256 + lane * 4) = e * 16.0f + p;   // exactly embed_kernel's expression
 }
 
-template <bool FAST>
+template <bool FAST, int NK>
 __global__ __launch_bounds__(256) void attn_step16_tab_kernel(const float* __restrict__ tab, int tab_len,
                                                               const int32_t* __restrict__ ys, int T, int bos, int vocab,
                                                               const int* __restrict__ idx, const int* __restrict__ n_dev,
-                                                              int pos, float* __restrict__ out) {
+                                                              float* __restrict__ out) {
+  constexpr int pos = NK - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= *n_dev) return;
@@ -267,41 +280,48 @@ __global__ __launch_bounds__(256) void attn_step16_tab_kernel(const float* __res
   int tokj = bos;
   if (lane >= 1 && lane <= pos) tokj = ys[(size_t)s * T + lane - 1];
   tokj = min(max(tokj, 0), vocab - 1);
-  f32x4 kr[16], vr[16];
+  f32x4 kr[NK], vr[NK];
   f32x4 qv;
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j <= pos) {  // uniform
-      const int t = __builtin_amdgcn_readlane(tokj, j);
-      const float* row = tab + ((size_t)t * tab_len + j) * 768 + lane * 4;
-      kr[j] = *(const f32x4*)(row + 256);
-      vr[j] = *(const f32x4*)(row + 512);
-      if (j == pos) qv = *(const f32x4*)row;
-    }
-  float sc[16];
+  for (int j = 0; j < NK; ++j) {
+    const int t = __builtin_amdgcn_readlane(tokj, j);
+    const float* row = tab + ((size_t)t * tab_len + j) * 768 + lane * 4;
+    kr[j] = *(const f32x4*)(row + 256);
+    vr[j] = *(const f32x4*)(row + 512);
+    if (j == pos) qv = *(const f32x4*)row;
+  }
+  float sc[NK];
   float m = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    sc[j] = -INFINITY;
-    if (j <= pos) {
-      const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
-      sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
-      m = fmaxf(m, sc[j]);
-    }
+  for (int j = 0; j < NK; ++j) {
+    const float part = fmaf(qv.x, kr[j].x, fmaf(qv.y, kr[j].y, fmaf(qv.z, kr[j].z, qv.w * kr[j].w)));
+    sc[j] = row16_sum(part) * 0.125f;  // / sqrt(d_k)
+    m = fmaxf(m, sc[j]);
   }
   float sum = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j <= pos) {
-      sc[j] = FAST ? __expf(sc[j] - m) : expf(sc[j] - m);
-      sum += sc[j];
-    }
+  for (int j = 0; j < NK; ++j) {
+    sc[j] = FAST ? __expf(sc[j] - m) : expf(sc[j] - m);
+    sum += sc[j];
+  }
   const float inv = 1.0f / sum;
   f32x4 o4 = {0, 0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j <= pos) o4 += (sc[j] * inv) * vr[j];
+  for (int j = 0; j < NK; ++j) o4 += (sc[j] * inv) * vr[j];
   *(f32x4*)(out + (size_t)r * 256 + lane * 4) = o4;
+}
+template <bool FAST>
+static void launch_attn_step16_tab(int nk, int n_bound, hipStream_t st, const float* tab, int tab_len, const int32_t* ys, int T, int bos,
+                                   int vocab, const int* idx, const int* n_dev, float* out) {
+  switch (nk) {
+#define ST_NK_CASE(N)                                                                                                          \
+  case N:                                                                                                                      \
+    hipLaunchKernelGGL((attn_step16_tab_kernel<FAST, N>), dim3((n_bound + 3) / 4), dim3(256), 0, st, tab, tab_len, ys, T, bos, vocab, \
+                       idx, n_dev, out);                                                                                       \
+    break;
+    ST_NK_CASES(ST_NK_CASE)
+#undef ST_NK_CASE
+  }
 }
 
 // general form (16 <= pos < 64): attn_step_kernel with the K / V rows of the emitted tokens
@@ -836,8 +856,7 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       if (l == 0 && use_tab) {
         // first layer: q | k | v of (token, position) from the table; no projection, no K / V cache rows
         if (pos < 16)
-          hipLaunchKernelGGL(attn_step16_tab_kernel<true>, dim3((n_bound + 3) / 4), dim3(256), 0, st, w->l0_table, w->l0_table_len,
-                             out_ids, T, bos, w->vocab, idx, n_dev, pos, ws.att);
+          launch_attn_step16_tab<true>(pos + 1, n_bound, st, w->l0_table, w->l0_table_len, out_ids, T, bos, w->vocab, idx, n_dev, ws.att);
         else
           hipLaunchKernelGGL(attn_step_tab_kernel, dim3(n_bound), dim3(256), 0, st, w->l0_table, w->l0_table_len, out_ids, T, bos,
                              w->vocab, idx, n_dev, pos, ws.att);
@@ -858,11 +877,9 @@ extern "C" int st_decode_greedy(const StDecoderWeights* w, const float* latent, 
       else
         ST_TRY((launch_rp<EPI_QKV, 8>(g, n_bound, qsplits, st)));
       if (pos < 16 && w->gemm_format == ST_GEMM_F16X3)
-        hipLaunchKernelGGL(attn_step16_kernel<true>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx,
-                           n_dev, pos, ws.att);
+        launch_attn_step16<true>(pos + 1, n_bound, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx, n_dev, ws.att);
       else if (pos < 16)
-        hipLaunchKernelGGL(attn_step16_kernel<false>, dim3((n_bound + 3) / 4), dim3(256), 0, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx,
-                           n_dev, pos, ws.att);
+        launch_attn_step16<false>(pos + 1, n_bound, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx, n_dev, ws.att);
       else
         hipLaunchKernelGGL(attn_step_kernel, dim3(n_bound), dim3(256), 0, st, ws.q, kb, vb, kv_stride, kv_pos_stride, idx, n_dev, pos,
                            ws.att);
