@@ -254,6 +254,12 @@ __device__ __forceinline__ f32x4 score_row(const ScorerArgs& a, int m0, int n, i
     const float* zp = j < np ? a.like_z + ((size_t)b * np + j) * 256 : a.unlike_z + ((size_t)b * nn + (j - np)) * 256;
     return *(const f32x4*)(zp + lane * 4);
   };
+  // --not_nll: the coefficients g_j = +-1 / (tau nt) do not depend on the scores, so sum_j g_j z_j is taken in THIS pass over
+  // the unit vectors (the same products and additions in the same order as the second pass below made them) and the
+  // vectors are read once per row instead of twice: 20 KB of the 44 KB a sentence costs the kernel per iteration.
+  const bool one_pass = (a.flags & ST_F_NOT_NLL) != 0;
+  const float c_nn = inv_tau / (float)nt;
+  f32x4 gs = {0, 0, 0, 0};
   for (int j0 = 0; j0 < nt; j0 += SC_ZCH) {
     f32x4 zc[SC_ZCH];
 #pragma unroll
@@ -264,6 +270,7 @@ __device__ __forceinline__ f32x4 score_row(const ScorerArgs& a, int m0, int n, i
         const f32x4 zj = zc[u];
         const float d = wave_sum(p.x * zj.x + p.y * zj.y + p.z * zj.z + p.w * zj.w);
         if (lane == 0) cosv[r * 32 + j0 + u] = d / pn;
+        if (one_pass) gs += (j0 + u < np ? c_nn : -c_nn) * zj;
       }
   }
   __builtin_amdgcn_wave_barrier();
@@ -272,7 +279,7 @@ __device__ __forceinline__ f32x4 score_row(const ScorerArgs& a, int m0, int n, i
   float g = 0.0f, lossv = 0.0f;
   if (a.flags & ST_F_NOT_NLL) {
     // loss_ref = (sum neg - sum pos) / (np + nn)      (siamese_contrastive.py:424-436)
-    const float c = inv_tau / (float)nt;
+    const float c = c_nn;
     if (lane < nt) g = lane < np ? c : -c;
     float sacc = 0.0f;
     for (int j = 0; j < nt; ++j) sacc += (j < np ? -1.0f : 1.0f) * cosv[r * 32 + j] * inv_tau;
@@ -315,19 +322,22 @@ __device__ __forceinline__ f32x4 score_row(const ScorerArgs& a, int m0, int n, i
   }
   if (lane < 32) coef[r * 32 + lane] = lane < nt ? g : 0.0f;
   __builtin_amdgcn_wave_barrier();
-  f32x4 gs = {0, 0, 0, 0};
   float gc = 0.0f;
-  for (int j0 = 0; j0 < nt; j0 += SC_ZCH) {
-    f32x4 zc[SC_ZCH];
+  if (one_pass) {
+    for (int j = 0; j < nt; ++j) gc += coef[r * 32 + j] * cosv[r * 32 + j];
+  } else {
+    for (int j0 = 0; j0 < nt; j0 += SC_ZCH) {
+      f32x4 zc[SC_ZCH];
 #pragma unroll
-    for (int u = 0; u < SC_ZCH; ++u) zc[u] = zrow(min(j0 + u, nt - 1));
+      for (int u = 0; u < SC_ZCH; ++u) zc[u] = zrow(min(j0 + u, nt - 1));
 #pragma unroll
-    for (int u = 0; u < SC_ZCH; ++u)
-      if (j0 + u < nt) {
-        const float gj = coef[r * 32 + j0 + u];
-        gs += gj * zc[u];
-        gc += gj * cosv[r * 32 + j0 + u];
-      }
+      for (int u = 0; u < SC_ZCH; ++u)
+        if (j0 + u < nt) {
+          const float gj = coef[r * 32 + j0 + u];
+          gs += gj * zc[u];
+          gc += gj * cosv[r * 32 + j0 + u];
+        }
+    }
   }
   const f32x4 dp = gs / pn - (gc / (pn * pn)) * p;
   if (lane == 0 && a.loss_out && m0 + r < n) a.loss_out[m0 + r] = lossv;
