@@ -75,10 +75,13 @@ def greedy_decode(ae, latent, max_len=60, start_id=2, eos=3, pad=0, early_exit=T
     return ids, gap, steps.value
 
 
-def encode_latent(ae, tokens, tok_pos, sent_off, n_sent, max_sent_len, ws: DecodeWorkspace = None):
-    """Packed tokens (int32 device tensors) -> latent [n_sent,256]."""
+def encode_latent(ae, tokens, tok_pos, sent_off, n_sent, max_sent_len, ws: DecodeWorkspace = None, out=None):
+    """Packed tokens (int32 device tensors) -> latent [n_sent,256] (written into `out`, a contiguous [n_sent,256] f32
+    tensor, when given: the chunks of a large batch go straight into their rows of one buffer)."""
     R = tokens.numel()
-    latent = torch.empty(n_sent, 256, dtype=torch.float32, device=sent_off.device)
+    if out is not None:
+        assert out.shape == (n_sent, 256) and out.dtype == torch.float32 and out.is_contiguous() and out.device == sent_off.device
+    latent = out if out is not None else torch.empty(n_sent, 256, dtype=torch.float32, device=sent_off.device)
     if n_sent == 0:
         return latent
     need = lib().st_encode_workspace_bytes(C.byref(ae.enc), R, n_sent)
