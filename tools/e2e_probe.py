@@ -16,7 +16,8 @@ sc = W.ScorerWeights(W.load_state_dict_file(os.path.join(GOLD, "siamese_model_pa
                      W.load_state_dict_file(os.path.join(GOLD, "predictor_net_params.safetensors")), dev)
 cfg = AttackConfig(not_nll=True, pos_victim_lr=0.2, neg_victim_lr=0.2, log_decodes=False, iters_per_decode=(12, 6))
 runner = AttackRunner(ae, sc, cfg, dev)
-B, NB = 49152, 4
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 49152      # sentences per batch
+NB = int(sys.argv[2]) if len(sys.argv) > 2 else 4         # batches
 counts = load_word_counts(os.path.join(GOLD, "yelp", "word_to_id.txt"), ae.vocab)
 data = AttackSet.synthetic(B * NB, ae.vocab, "yelp", seed=99, word_counts=counts)
 with contextlib.redirect_stdout(sys.stderr):
