@@ -86,8 +86,8 @@ class LogWriter:
 
     def write_block(self, block):
         """a pre-formatted block of records (format_attack_block): bytes with prefix and newlines"""
-        raw = block.tobytes() if hasattr(block, "tobytes") else bytes(block)
         if self.echo or not self.f:
+            raw = block.tobytes() if hasattr(block, "tobytes") else bytes(block)
             msgs = [l[len(LOG_PREFIX):] for l in raw.decode("utf-8").split("\n")[:-1]]
             if self.echo:
                 print("\n".join(msgs))
@@ -95,7 +95,12 @@ class LogWriter:
                 self.lines.extend(msgs)
         if self.f:
             self.f.flush()
-            self.f.buffer.write(raw)
+            # (a contiguous byte array goes to the file as it is: tobytes() copied 265 MB per 98 304-sentence batch)
+            flags = getattr(block, "flags", None)
+            if flags is not None and flags["C_CONTIGUOUS"]:
+                self.f.buffer.write(memoryview(block))
+            else:
+                self.f.buffer.write(block.tobytes() if hasattr(block, "tobytes") else bytes(block))
             self.f.buffer.flush()
 
     def __call__(self, msg: str):
