@@ -94,8 +94,26 @@ def test_every_gradient_element_matches_the_oracle(dev, B, Kp, Kn, kw):
     masks = rng.random((1 + Kp + Kn, 2, B, 512)) >= 0.2
     loss, choice, grads, stats = T.scorer_train_loss_and_grads(ssd, psd, ori, like, unlike, masks, **kw)
     tr = _trainer(dev, ssd, psd, **kw)
-    ch = tr.loss_and_grads(_dev(ori, dev), _dev(like, dev), _dev(unlike, dev), keep_masks=_dev(masks.astype(np.uint8), dev))
+    args = (_dev(ori, dev), _dev(like, dev), _dev(unlike, dev))
+    km = _dev(masks.astype(np.uint8), dev)
+    if B in (64, 130):
+        # the one-element-per-load form of the small products (it serves misaligned operands, which this interface never
+        # produces): same contraction order, so the step must come out bit-identical to the four-per-load form
+        import ctypes as C
+        from style_transfer_amd import _lib
+        sw = C.c_int.in_dll(_lib.lib(), "g_tr_scalar_gemm")
+        sw.value = 1
+        try:
+            tr.loss_and_grads(*args, keep_masks=km)
+            torch.cuda.synchronize()
+            g_scalar, l_scalar = tr.grads.clone(), tr.loss.clone()
+        finally:
+            sw.value = 0
+        tr = _trainer(dev, ssd, psd, **kw)
+    ch = tr.loss_and_grads(*args, keep_masks=km)
     torch.cuda.synchronize()
+    if B in (64, 130):
+        assert torch.equal(tr.grads, g_scalar) and torch.equal(tr.loss, l_scalar)
     # B = 2 is BatchNorm's degenerate minimum (x_hat = +-1 up to eps: 1/sqrt(var + eps) amplifies rounding)
     assert abs(float(tr.loss.item()) - loss) <= (5e-6 if B > 2 else 1e-4) * abs(loss)
     if B > 2:      # with two rows BatchNorm maps everything to +-1 and ties in the scores are common
