@@ -21,7 +21,7 @@ python3 - <<'PY' | tee -a gpurun_out/st128/summary.txt
 import csv
 rows=list(csv.DictReader(open('gpurun_out/st128/st_kernel_trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-n=32
+n=27
 last=rows[-n:]
 t0=int(last[0]['Start_Timestamp'])
 for r in last:
