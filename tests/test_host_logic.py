@@ -404,6 +404,19 @@ def test_log_formatter_matches_the_python_writer(id_to_word):
         w2 = LogWriter(None, echo=False)
         w2.write_block(block)
         assert w2.lines == w.lines
+        # to a file: the byte array itself (no copy), a strided view of it and plain bytes all land as the same text,
+        # between lines written the ordinary way
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "log")
+            w3 = LogWriter(path, echo=False)
+            w3("head")
+            w3.write_block(block)
+            w3.write_block(np.repeat(block, 2)[::2])
+            w3.write_block(block.tobytes())
+            w3("tail")
+            w3.close()
+            assert open(path, "rb").read().decode("utf-8") == LOG_PREFIX + "head\n" + want * 3 + LOG_PREFIX + "tail\n"
 
 
 def test_bench_self_launch_control_flow_without_a_gpu():
