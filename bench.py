@@ -86,6 +86,7 @@ def parse_args(argv=None):
     ap.add_argument("--iters-per-decode", default="12,6", help="edit iterations decoded per round: an int or a schedule like 9,5,4")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-defer-stragglers", action="store_true", help="A/B: sentences whose decodes do not end stay in their rounds (AttackConfig.defer_stragglers=False)")
+    ap.add_argument("--no-split-by-length", action="store_true", help="A/B: mixed-length encoder chunks stay whole (AttackConfig.split_by_length=False)")
     ap.add_argument("--sync-every", type=int, default=None, help="decode steps between two host reads of the live count (default: the package's)")
     ap.add_argument("--same-batch", action="store_true",
                     help="reuse ONE synthetic batch for every step (round-1 behaviour); default: a different batch per step, all "
@@ -353,6 +354,8 @@ def main(argv=None):
         cfg.sync_every = a.sync_every
     if a.no_defer_stragglers:
         cfg.defer_stragglers = False
+    if a.no_split_by_length:
+        cfg.split_by_length = False
     runner = AttackRunner(ae, scorer, cfg, dev)
     B = a.batch
     counts = None

@@ -62,6 +62,7 @@ class AttackConfig:
     single_round_max_batch: int = 8192
     merge_log_decodes_max_bytes: float = 150e9   # decode workspace up to which the log decodes join round 1 (121 / 241 KB per job)
     defer_stragglers: bool = True  # see run_prepared: sentences whose decodes do not end are finished in an extra round
+    split_by_length: bool = True   # see prepare: short and long sentences of a mixed chunk are encoded apart
     count_units: bool = False
 
     @classmethod
@@ -212,10 +213,19 @@ class AttackRunner:
 
     # -- pieces -----------------------------------------------------------------------------------
     ENC_CHUNK = 32768  # sentences per encoder launch sequence (bounds the [rows, d_ff] workspace)
+    # The fused encoder kernels (QKV projection + attention in one launch, first layer from the (token, position) table:
+    # csrc/st_encode.hip) take a launch whose sentences all have <= 16 tokens.  A chunk that mixes lengths (amazon:
+    # references of up to 31 tokens, 65 % of them <= 16) is encoded as two launches, short and long sentences apart, and
+    # the latents go to their rows by index; a sentence's latent does not depend on what shares its launch.
+    SHORT_LEN = 16
+    SPLIT_MIN = 1024   # short sentences a mixed chunk must hold before it is split
 
     def prepare(self, batch: AttackSet):
         """Host -> device: pack the 1 + K+ + K- sentences of every origin (order: all origins, all
-        like groups, all unlike groups) into device token arrays, in chunks of ENC_CHUNK sentences."""
+        like groups, all unlike groups) into device token arrays, in chunks of ENC_CHUNK sentences.
+        A chunk is (tokens, tok_pos, sent_off, n_sent, max_len, row0, dest): latents go to rows row0 .. row0 + n_sent - 1
+        of the batch's latent array, or to rows `dest` (int64 device tensor) when the chunk is one length class of a
+        mixed span."""
         sents = batch.all_sentences()            # one flat token array + offsets (data.Ragged): no per-sentence Python
         dev, chunks, host = self.device, [], []
 
@@ -227,26 +237,38 @@ class AttackRunner:
             pin.copy_(src)
             host.append(pin)
             return pin.to(dev, non_blocking=True)
+        split_ok = self.cfg.split_by_length and self.ae.gemm_format == "f16x3"
         for c0 in range(0, len(sents), self.ENC_CHUNK):
             c1 = min(len(sents), c0 + self.ENC_CHUNK)
-            tokens, tok_pos, sent_off, max_len = pack_sentences(sents.span(c0, c1))
-            chunks.append((h2d(tokens), h2d(tok_pos), h2d(sent_off), c1 - c0, max_len))
-        return dict(chunks=chunks, B=len(batch), kp=batch.n_pos, kn=batch.n_neg, _host=host)
+            span = sents.span(c0, c1)
+            lens = span.lens
+            short = lens <= self.SHORT_LEN
+            n_short = int(short.sum())
+            if split_ok and self.SPLIT_MIN <= n_short < c1 - c0:
+                for idx in (np.nonzero(short)[0], np.nonzero(~short)[0]):
+                    tokens, tok_pos, sent_off, max_len = pack_sentences(span.take(idx))
+                    chunks.append((h2d(tokens), h2d(tok_pos), h2d(sent_off), int(idx.size), max_len, c0, h2d(idx.astype(np.int64) + c0)))
+            else:
+                tokens, tok_pos, sent_off, max_len = pack_sentences(span)
+                chunks.append((h2d(tokens), h2d(tok_pos), h2d(sent_off), c1 - c0, max_len, c0, None))
+        return dict(chunks=chunks, n_sent=len(sents), B=len(batch), kp=batch.n_pos, kn=batch.n_neg, _host=host)
 
     def encode_prepared(self, prep):
         cur = torch.cuda.current_stream(self.device)
-        for (t, p, o, _, _) in prep["chunks"]:      # a prefetch thread may have allocated them on its side stream
-            for x in (t, p, o):
-                x.record_stream(cur)
         chunks = prep["chunks"]
+        for c in chunks:      # a prefetch thread may have allocated them on its side stream
+            for x in (c[0], c[1], c[2], c[6]):
+                if x is not None:
+                    x.record_stream(cur)
         if len(chunks) == 1:
-            t, p, o, n, mx = chunks[0]
+            t, p, o, n, mx, _, _ = chunks[0]
             return ops.encode_latent(self.ae, t, p, o, n, mx, ws=self.ws)
-        lat = torch.empty(sum(c[3] for c in chunks), 256, dtype=torch.float32, device=self.device)   # (no torch.cat: 2 GB per 98 304-sentence batch)
-        r0 = 0
-        for (t, p, o, n, mx) in chunks:
-            ops.encode_latent(self.ae, t, p, o, n, mx, ws=self.ws, out=lat[r0:r0 + n])
-            r0 += n
+        lat = torch.empty(prep["n_sent"], 256, dtype=torch.float32, device=self.device)   # (no torch.cat: 2 GB per 98 304-sentence batch)
+        for (t, p, o, n, mx, row0, dest) in chunks:
+            if dest is None:
+                ops.encode_latent(self.ae, t, p, o, n, mx, ws=self.ws, out=lat[row0:row0 + n])
+            else:
+                lat.index_copy_(0, dest, ops.encode_latent(self.ae, t, p, o, n, mx, ws=self.ws))
         return lat
 
     def encode(self, sents):

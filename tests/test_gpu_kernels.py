@@ -658,6 +658,36 @@ def test_first_layer_table_gives_the_same_decodes(dev, ae_sd_torch, gold_notnll)
     assert torch.equal(a, b) and torch.equal(ga, gb)
 
 
+@pytest.mark.gpu
+def test_mixed_length_chunks_encoded_apart_give_the_same_latents(dev, ae):
+    """AttackRunner.prepare splits a chunk that mixes sentences of <= 16 tokens with longer ones into two launches
+    (short: the fused QKV + attention kernels and the first-layer table) and sends the latents to their rows by index.
+    Against the unsplit chunk: every row filled, the long sentences bit-identical (same kernels, other neighbours), the
+    short ones within 2e-6 of the row's norm (another kernel family computes them)."""
+    from style_transfer_amd.attack import AttackConfig, AttackRunner
+    from style_transfer_amd.data import AttackSet, Ragged
+    rng = np.random.default_rng(3)
+    n = 6000
+    lens = np.where(rng.random(n) < 0.6, rng.integers(1, 17, n), rng.integers(17, 32, n)).astype(np.int64)
+    rag = Ragged.from_lengths(rng.integers(4, ae.vocab, int(lens.sum()), dtype=np.int32), lens)
+    none = Ragged(np.zeros(0, np.int32), np.zeros(1, np.int64))
+    data = AttackSet(rag, none, none, None, 0, 0)
+    lat = {}
+    for split in (True, False):
+        r = AttackRunner(ae, None, AttackConfig(split_by_length=split), dev)
+        r.ENC_CHUNK = 4096                       # two chunks: one split call each, then the rows of both
+        prep = r.prepare(data)
+        assert len(prep["chunks"]) == (4 if split and ae.gemm_format == "f16x3" else 2)   # (the fused kernels are f16x3 only)
+        lat[split] = r.encode_prepared(prep).cpu().numpy()
+    a, b = lat[True], lat[False]
+    assert a.shape == b.shape == (n, 256) and np.isfinite(a).all()
+    long_ = lens > 16
+    assert np.array_equal(a[long_], b[long_])
+    err = np.abs(a[~long_] - b[~long_]).max(1) / np.linalg.norm(b[~long_], axis=1)
+    print("short sentences, split against unsplit: worst |d latent| / |latent| = %.2e" % err.max())
+    assert err.max() < 2e-6
+
+
 def test_first_encoder_layer_table_gives_the_same_latents(dev, ae_sd_torch):
     """StEncoderWeights.l0_table: the first encoder layer's q | k | v per (token, position) from a table instead of a
     projection per row.  Short sentences (<= 16 tokens: the attention block of the fused kernel on gathered rows) and long
