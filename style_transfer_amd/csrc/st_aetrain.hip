@@ -37,6 +37,7 @@ int g_ae_force_redo = 0;  // tests: the range flag starts at 1, so every split-f
 int g_ae_rp = 1;          // ST_AE_NO_RP -> 0: strided GEMM for forward and dX
 int g_ae_dw = 2;          // ST_AE_NO_DW -> 0: strided GEMM + column sums; ST_AE_DW_DIRECT -> 1: operands straight from global memory; 2: through LDS
 int g_ae_att16 = 1;       // ST_AE_NO_ATT16 -> 0: lane-per-row attention kernels for every sentence
+int g_ae_views = 1;       // ST_AE_VIEW_LOOP -> 0: one pair of in-batch-loss launches per view (small batches too)
 static void ae_env() {
   static bool done = false;
   if (done) return;
@@ -46,6 +47,7 @@ static void ae_env() {
   if (getenv("ST_AE_DW_DIRECT")) g_ae_dw = 1;
   if (getenv("ST_AE_NO_DW")) g_ae_dw = 0;
   if (getenv("ST_AE_NO_ATT16")) g_ae_att16 = 0;
+  if (getenv("ST_AE_VIEW_LOOP")) g_ae_views = 0;
 }
 
 namespace {
@@ -640,6 +642,14 @@ __global__ __launch_bounds__(256) void ae_relu_drop_bwd_kernel(float* __restrict
 __global__ __launch_bounds__(256) void ae_add_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e < n) a[e] += b[e];
+}
+// a += parts[0] + parts[1] + ..., added one after the other as nv calls of ae_add_kernel would
+__global__ __launch_bounds__(256) void ae_add_views_kernel(float* __restrict__ a, const float* __restrict__ parts, int nv, long n) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = a[e];
+  for (int v = 0; v < nv; ++v) s += parts[(size_t)v * n + e];
+  a[e] = s;
 }
 
 // latent[s] = sum over the sentence's rows of sigmoid(y[row])     (model.py:236-240)  block per sentence, thread = feature
@@ -1514,7 +1524,15 @@ extern "C" int st_ae_train_step(const StAeParams* p, const StAeParams* g, float*
   // ---------------- constraint: the (views) B x B similarity blocks ----------------
   ST_HIP(hipMemsetAsync(w.dlat, 0, (size_t)Se * 1024, c.st));
   hipLaunchKernelGGL(ae_fill_kernel, ELEMS((long)B), w.sl_g, (long)B, bata / ((float)B * (float)n_views));
-  for (int v = 0; v < n_views; ++v) {
+  const bool views_at_once = g_ae_views && sl_small_views_ok(B) && (size_t)n_views * B * 257 <= w.slab_floats;
+  if (views_at_once) {  // (the slab of the split contractions is free here: d_ori per view, then the views' log-sum-exps)
+    float* parts = w.slab;
+    float* lse_v = w.slab + (size_t)n_views * B * 256;
+    ST_TRY(sl_small_views(w.lat, w.lat + (size_t)B * 256, n_views, B, tau, w.con_rows, lse_v, w.sl_g, parts, w.dlat + (size_t)B * 256, c.st));
+    hipLaunchKernelGGL(ae_add_views_kernel, ELEMS((long)B * 256), w.dlat, (const float*)parts, n_views, (long)B * 256);
+    ST_LAUNCH_CHECK();
+  }
+  for (int v = 0; v < n_views && !views_at_once; ++v) {
     const float* like = w.lat + (size_t)(1 + v) * B * 256;
     float* dlike = w.dlat + (size_t)(1 + v) * B * 256;
     ST_TRY(st_simloss_fwd(w.lat, like, B, B, tau, 0, w.con_rows + (size_t)v * B, w.sl_lse, w.sl_scratch, w.sl_scratch_bytes, c.st));

@@ -13,6 +13,10 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 void st_set_error(const char* fmt, ...);
+// internal, not part of the C-ABI (csrc/st_simloss.hip; used by csrc/st_aetrain.hip)
+bool sl_small_views_ok(int B);
+int sl_small_views(const float* ori, const float* like0, int n_views, int B, float tau, float* loss_rows, float* lse, const float* g,
+                   float* d_ori_parts, float* d_like0, hipStream_t st);
 
 #define ST_CHECK_ARG(cond, ...)   \
   do {                            \

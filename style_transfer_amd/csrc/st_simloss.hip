@@ -93,10 +93,16 @@ __device__ __forceinline__ f32x4 sl_unit(const float* __restrict__ x, int r, int
   return v / nrm;
 }
 __device__ __forceinline__ float sl_dot(const f32x4& a, const f32x4& b) { return wave_sum(a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w); }
+// blockIdx.y = view: its keys at like + y * like_vs, its outputs at loss / lse + y * out_vs (sl_small_views: the views of
+// the AE constraint share their queries and go out as one launch; a single block has strides 0 and gridDim.y = 1)
 __global__ __launch_bounds__(256) void sl_small_fwd_kernel(const float* __restrict__ ori, const float* __restrict__ like, int Bq, int Bk,
-                                                           float scale, int row_offset, float* __restrict__ loss, float* __restrict__ lse) {
+                                                           float scale, int row_offset, float* __restrict__ loss, float* __restrict__ lse,
+                                                           long like_vs, int out_vs) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= Bq) return;
+  like += blockIdx.y * like_vs;
+  loss += blockIdx.y * out_vs;
+  lse += blockIdx.y * out_vs;
   const int lane = threadIdx.x & 63;
   float nn;
   const f32x4 u = sl_unit(ori, i, lane, nn);
@@ -130,7 +136,12 @@ __global__ __launch_bounds__(256) void sl_small_fwd_kernel(const float* __restri
 // blocks [0, ceil(Bq / 4)): wave per query -> d_ori;  the rest: wave per key -> d_like +=
 __global__ __launch_bounds__(256) void sl_small_bwd_kernel(const float* __restrict__ ori, const float* __restrict__ like, int Bq, int Bk,
                                                            float scale, int row_offset, const float* __restrict__ lse,
-                                                           const float* __restrict__ g, float* __restrict__ d_ori, float* __restrict__ d_like) {
+                                                           const float* __restrict__ g, float* __restrict__ d_ori, float* __restrict__ d_like,
+                                                           long like_vs, int lse_vs, long dori_vs) {
+  like += blockIdx.y * like_vs;
+  d_like += blockIdx.y * like_vs;
+  lse += blockIdx.y * lse_vs;
+  d_ori += blockIdx.y * dori_vs;
   const int qblocks = (Bq + 3) / 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   f32x4 acc = {0, 0, 0, 0};
@@ -186,6 +197,21 @@ __global__ __launch_bounds__(256) void sl_small_bwd_kernel(const float* __restri
   }
 }
 int g_sl_small = 1;  // 0: small blocks through the GEMM path as well (tests flip it)
+// internal (st_common.h): n_views blocks of B queries x B keys that share the queries, keys of view v at like0 + v B 256
+// (the AE constraint, st_aetrain.hip): one forward and one backward launch for all of them instead of one pair per view
+// (at B = 128 a view's launches are 32 + 64 workgroups of 49 + 38 us: eleven views in a row were 18 % of the step).
+// loss_rows, lse: [n_views][B]; d_ori_parts: [n_views][B][256] (the caller adds them up in view order); d_like0 += per view.
+bool sl_small_views_ok(int B) { return g_sl_small && B <= SL_SMALL && B % 32 == 0; }
+int sl_small_views(const float* ori, const float* like0, int n_views, int B, float tau, float* loss_rows, float* lse, const float* g,
+                   float* d_ori_parts, float* d_like0, hipStream_t st) {
+  ST_CHECK_ARG(sl_small_views_ok(B) && n_views >= 1 && n_views <= 65535 && tau > 0.0f, "sl_small_views: B=%d n_views=%d", B, n_views);
+  const long vs = (long)B * 256;
+  hipLaunchKernelGGL(sl_small_fwd_kernel, dim3((B + 3) / 4, n_views), dim3(256), 0, st, ori, like0, B, B, 1.0f / tau, 0, loss_rows, lse, vs, B);
+  hipLaunchKernelGGL(sl_small_bwd_kernel, dim3(2 * ((B + 3) / 4), n_views), dim3(256), 0, st, ori, like0, B, B, 1.0f / tau, 0,
+                     (const float*)lse, g, d_ori_parts, d_like0, vs, B, vs);
+  ST_LAUNCH_CHECK();
+  return ST_OK;
+}
 
 // Operand format of the similarity GEMMs (ST_GEMM_*).  F16X3 (default): unit rows lie in [-1, 1] and dS in [-1, 1], the
 // ideal domain of the hi + lo split (f32-grade: ~2^-22 per term), and every product of the block runs on the f16 MFMA.
@@ -669,7 +695,7 @@ extern "C" int st_simloss_fwd(const float* ori, const float* like, int Bq, int B
   ST_CHECK_ARG(loss && lse, "NULL output");
   hipStream_t st = (hipStream_t)stream;
   if (g_sl_small && Bq <= SL_SMALL && Bk <= SL_SMALL) {
-    hipLaunchKernelGGL(sl_small_fwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, like, Bq, Bk, 1.0f / tau, row_offset, loss, lse);
+    hipLaunchKernelGGL(sl_small_fwd_kernel, dim3((Bq + 3) / 4), dim3(256), 0, st, ori, like, Bq, Bk, 1.0f / tau, row_offset, loss, lse, 0L, 0);
     ST_LAUNCH_CHECK();
     return ST_OK;
   }
@@ -709,7 +735,7 @@ extern "C" int st_simloss_bwd(const float* ori, const float* like, int Bq, int B
   hipStream_t st = (hipStream_t)stream;
   if (g_sl_small && Bq <= SL_SMALL && Bk <= SL_SMALL) {
     hipLaunchKernelGGL(sl_small_bwd_kernel, dim3((Bq + 3) / 4 + (Bk + 3) / 4), dim3(256), 0, st, ori, like, Bq, Bk, 1.0f / tau, row_offset,
-                       lse, g, d_ori, d_like);
+                       lse, g, d_ori, d_like, 0L, 0, 0L);
     ST_LAUNCH_CHECK();
     return ST_OK;
   }

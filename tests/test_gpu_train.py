@@ -336,7 +336,7 @@ def test_ae_train_step_with_dropout_matches_the_oracle(ae_sd_torch, ae_sd):
 # 5e-3 jumps in the same tensors (tools/ae_fwd_format_probe2.py); on the reference's golden batch the two formats agree
 # to 2e-6 (tools/ae_fwd_format_probe.py) and both meet the reference's gradients to the same 1e-4.
 AE_FORMS = [("g_ae_att16", 0, 2e-2), ("g_ae_dw", 1, 2e-5), ("g_ae_dw", 0, 2e-5), ("g_ae_fwd_h", 0, 2e-2), ("g_ae_force_redo", 1, 2e-2),
-            ("g_ae_rp", 0, 2e-2)]
+            ("g_ae_rp", 0, 2e-2), ("g_ae_views", 0, 0.0)]
 
 
 def test_ae_train_step_kernel_forms_agree(ae_sd_torch):
@@ -380,8 +380,9 @@ def test_ae_train_step_kernel_forms_agree(ae_sd_torch):
             if AC.is_noise(n) or AC.is_zero(n):
                 assert float(a.norm()) < 1e-6 and nb < 1e-6, (name, value, n)
             else:
-                assert float((a - b).norm()) < tol * nb, (name, value, n, float((a - b).norm()), nb)
+                assert float((a - b).norm()) <= tol * nb, (name, value, n, float((a - b).norm()), nb)
     assert torch.equal(got[("g_ae_force_redo", 1)], got[("g_ae_fwd_h", 0)]), "the forced exact-f32 redo differs from the exact-f32 forward"
+    assert torch.equal(got[("g_ae_views", 0)], g0), "the in-batch-loss views in one launch differ from one launch pair per view"
     rec1, con1, g1 = run()
     assert rec1 == rec0 and con1 == con0 and torch.equal(g1, g0), "the shipped step is not bit-reproducible"
 
