@@ -298,6 +298,62 @@ def test_accept_changes(dev):
     assert np.array_equal(rec.cpu().numpy()[:5], a[:5])
 
 
+@pytest.mark.parametrize("T", [59, 64, 7, 80])
+def test_accept_changes_wave_and_thread_forms_agree(dev, T):
+    """The wave-per-sentence kernel (rows of <= 64 ids) against the thread-per-sentence walk on random rows built to hit
+    every branch: equal prefixes with junk behind the terminator, EOS against PAD, one side longer, ids beyond the
+    vocabulary, ids that spell the same word (canon map), rows without a terminator, inactive rows, the --retext
+    confirmation and the change cap.  T = 80 takes the thread form in both runs (longer rows than a wave holds)."""
+    import ctypes as C
+    from style_transfer_amd import _lib, ops
+    rng = np.random.default_rng(T)
+    B, V = 4000, 50
+    base = rng.integers(4, V + 6, (B, T)).astype(np.int32)            # some ids >= V -> UNK
+
+    def with_end(rows):
+        rows = rows.copy()
+        n = rng.integers(0, T + 6, B)                                   # terminator position (>= T: none)
+        for i in range(B):
+            if n[i] < T:
+                rows[i, n[i]] = 3 if rng.random() < 0.6 else 0
+        return rows
+    acc = with_end(base)
+    new = acc.copy()
+    mode = rng.integers(0, 6, B)
+    for i in range(B):
+        if mode[i] == 1:                                              # change one id somewhere
+            new[i, rng.integers(0, T)] = rng.integers(4, V)
+        elif mode[i] == 2:                                            # move the terminator
+            new[i] = with_end(base)[i]
+        elif mode[i] == 3:                                            # junk behind the first terminator only
+            e = np.nonzero((acc[i] == 3) | (acc[i] == 0))[0]
+            if e.size:
+                new[i, e[0] + 1:] = rng.integers(0, V, T - e[0] - 1)
+        elif mode[i] == 4:                                            # swap EOS and PAD
+            new[i] = np.where(acc[i] == 3, 0, np.where(acc[i] == 0, 3, acc[i]))
+    canon = np.arange(V, dtype=np.int32)
+    canon[10:20] = canon[20:30]                                       # ten pairs of ids spell the same word
+    conf = np.where(rng.random((B, 1)) < 0.5, new, with_end(base)).astype(np.int32)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    sw = C.c_int.in_dll(_lib.lib(), "g_accept_thread_form")
+    out = {}
+    for form in (0, 1):
+        acc_d, n_ch = t(acc), t((np.arange(B) % 7).astype(np.int32))
+        changed = torch.zeros(B, dtype=torch.uint8, device=dev)
+        active = t((np.arange(B) % 5 != 0).astype(np.uint8))
+        rec = torch.full((B, T), -1, dtype=torch.int32, device=dev)
+        sw.value = form
+        try:
+            ops.accept_changes(t(new), acc_d, V, n_ch, changed, active, max_change=7, canon=t(canon), rec_ids=rec, confirm_ids=t(conf))
+            torch.cuda.synchronize()
+        finally:
+            sw.value = 0
+        out[form] = [x.cpu().numpy() for x in (acc_d, n_ch, changed, active, rec)]
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert 0.03 < out[0][2].mean() < 0.9                              # both outcomes occur
+
+
 @pytest.fixture(params=["f16x3", "f32"])
 def sl_fmt(request):
     """both operand formats of the similarity products meet the same tolerances"""
