@@ -75,7 +75,7 @@ __device__ __forceinline__ void tg_gemm_body(const TgArgs& a, const int bx, cons
   const int r0 = bz * a.rper, r1 = min(a.R, r0 + a.rper);
   const bool a_r_fast = a.sar == 1, b_r_fast = a.sbr == 1;
   // LDS row stride: TS + 4 keeps 16-byte rows for the vector writes of an operand whose unit stride runs along the tile;
-  // TS + 1 lets the 16 x 4 (r, i) lanes of an r-fast operand's writes fall on 64 different banks
+  // TS + 1 lets the 16 x 4 (r, i) lanes of an r-fast operand's four-row writes (VEC) fall on 64 different banks
   const int lda = a_r_fast ? TS + 1 : TS + 4, ldb = b_r_fast ? TS + 1 : TS + 4;
   float* const As = smem;
   float* const Bs = smem + TG_KS * (TS + 4);
