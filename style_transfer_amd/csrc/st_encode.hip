@@ -32,29 +32,46 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(const float* __restrict_
 // P is normalised before the product, as the reference multiplies softmax(scores) by V (model.py attention()).
 // qkv rows: [q | k | v] (768 floats).  The previous VALU kernel (keys in registers, one query at a time, 12 LDS-crossbar
 // shuffles per query) ran the amazon shape at 1.43 ms per launch; this one is bound by the qkv row traffic.
+// Where the [q | k | v] rows of a launch live: the projected rows (qkv, row r at r * 768), or - first layer with the
+// (token, position) table - the table itself, row r at (tok[r] * tab_len + pos[r]) * 768: the attention kernels read the
+// table rows where they lie (a gather into qkv first wrote and re-read 3 KB per token: 3.6 % of the amazon-shaped step).
+struct EncRowSrc {
+  const float* qkv;
+  const float* tab;
+  int tab_len, vocab;
+  const int32_t* tok;
+  const int32_t* pos;
+};
+__device__ __forceinline__ int enc_row_index(const EncRowSrc& s, int r) {
+  if (!s.tab) return r;
+  const int t = min(max(s.tok[r], 0), s.vocab - 1), p = min(max(s.pos[r], 0), s.tab_len - 1);
+  return t * s.tab_len + p;  // (< 2^31: the table is at most 8 GB of 3 KB rows)
+}
 template <bool FAST>  // as in enc_attn16_kernel below
-__global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
-                                                       int n_rows, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void enc_attn_kernel(EncRowSrc src, const int32_t* __restrict__ off, int n_rows, float* __restrict__ out) {
+  __shared__ int rowix[64];
   const int s = blockIdx.x;
   const int r0 = off[s], len = off[s + 1] - r0;
   if (len <= 16 || len > 64) return;  // short sentences: enc_attn16_kernel
   if (r0 < 0 || r0 + len > n_rows) return;  // bad offsets (flagged by enc_check_len_kernel): touch nothing
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const float* base = qkv + (size_t)r0 * 768 + h * 64;
+  if (threadIdx.x < 64) rowix[threadIdx.x] = enc_row_index(src, r0 + min((int)threadIdx.x, len - 1));
+  __syncthreads();
+  const float* base = (src.tab ? src.tab : src.qkv) + h * 64;  // row j of the sentence: base + rowix[j] * 768
   const int nt = (len + 31) >> 5;  // 32-row tiles of queries and of keys: 1 or 2
   f32x4 kf[2][8];
 #pragma unroll
   for (int kj = 0; kj < 2; ++kj)
     if (kj < nt) {
-      const float* kp = base + (size_t)min(kj * 32 + l31, len - 1) * 768 + 256 + half * 32;
+      const float* kp = base + (size_t)rowix[min(kj * 32 + l31, len - 1)] * 768 + 256 + half * 32;
 #pragma unroll
       for (int c = 0; c < 8; ++c) kf[kj][c] = *(const f32x4*)(kp + c * 4);
     }
   for (int qi = 0; qi < nt; ++qi) {
     f32x4 qf[8];
     {
-      const float* qp = base + (size_t)min(qi * 32 + l31, len - 1) * 768 + half * 32;
+      const float* qp = base + (size_t)rowix[min(qi * 32 + l31, len - 1)] * 768 + half * 32;
 #pragma unroll
       for (int c = 0; c < 8; ++c) qf[c] = *(const f32x4*)(qp + c * 4);
     }
@@ -99,7 +116,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
           float vv[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            vv[r] = base[(size_t)min(kj * 32 + mfma32_row(r, lane), len - 1) * 768 + 512 + dt * 32 + l31];
+            vv[r] = base[(size_t)rowix[min(kj * 32 + mfma32_row(r, lane), len - 1)] * 768 + 512 + dt * 32 + l31];
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc = mfma32(sacc[kj][r] * inv, vv[r], oacc);
         }
@@ -120,26 +137,28 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
 // rounded expf, whose ~20 instructions per call were a quarter of this kernel (encoder setup 87 -> 84 ms per step);
 // the exact-f32 format keeps expf.
 template <bool FAST>
-__global__ __launch_bounds__(256) void enc_attn16_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ off,
-                                                         int n_sent, int n_rows, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void enc_attn16_kernel(EncRowSrc src, const int32_t* __restrict__ off, int n_sent, int n_rows,
+                                                         float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n_sent) return;
   const int r0 = off[s], len = off[s + 1] - r0;
   if (len <= 0 || len > 16) return;
   if (r0 < 0 || r0 + len > n_rows) return;  // bad offsets (flagged by enc_check_len_kernel): touch nothing
-  const float* base = qkv + (size_t)r0 * 768 + lane * 4;
+  const float* base = (src.tab ? src.tab : src.qkv) + lane * 4;
+  auto row = [&](int j) { return base + (size_t)enc_row_index(src, r0 + j) * 768; };  // (wave-uniform index)
   f32x4 kr[16], vr[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j)
     if (j < len) {  // uniform
-      kr[j] = *(const f32x4*)(base + (size_t)j * 768 + 256);
-      vr[j] = *(const f32x4*)(base + (size_t)j * 768 + 512);
+      const float* rj = row(j);
+      kr[j] = *(const f32x4*)(rj + 256);
+      vr[j] = *(const f32x4*)(rj + 512);
     }
-  f32x4 qn = *(const f32x4*)base;
+  f32x4 qn = *(const f32x4*)row(0);
   for (int i = 0; i < len; ++i) {
     const f32x4 qv = qn;
-    if (i + 1 < len) qn = *(const f32x4*)(base + (size_t)(i + 1) * 768);
+    if (i + 1 < len) qn = *(const f32x4*)row(i + 1);
     float sc[16];
     float m = -INFINITY;
 #pragma unroll
@@ -734,7 +753,10 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       g.X = x; g.n_host = R; g.ln_a = y.ln0_a; g.ln_b = y.ln0_b; g.W = y.wqkv; g.bias = y.bqkv; g.N = 768;
       g.out = qkv; g.ldo = 768;
       const int qsplits = rp_splits(R, 768, 3, rp_nw(w->gemm_format, 8));
-      if (tab0) {
+      EncRowSrc src = {qkv, nullptr, 0, 0, nullptr, nullptr};
+      if (tab0 && !rp_enc_tab_gather) {
+        src.tab = w->l0_table; src.tab_len = w->l0_table_len; src.vocab = w->vocab; src.tok = tokens; src.pos = tok_pos;
+      } else if (tab0) {
         hipLaunchKernelGGL(enc_tab_gather_kernel, dim3((R + 3) / 4), dim3(256), 0, st, w->l0_table, w->l0_table_len, w->vocab, tokens,
                            tok_pos, R, qkv);
         ST_LAUNCH_CHECK();
@@ -743,14 +765,14 @@ extern "C" int st_encode_latent(const StEncoderWeights* w, const int32_t* tokens
       else
         ST_TRY((launch_rp<EPI_BIAS, 8>(g, R, qsplits, st)));
       if (w->gemm_format == ST_GEMM_F16X3)
-        hipLaunchKernelGGL(enc_attn16_kernel<true>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, R, att);
+        hipLaunchKernelGGL(enc_attn16_kernel<true>, dim3((n_sent + 3) / 4), dim3(256), 0, st, src, sent_off, n_sent, R, att);
       else
-        hipLaunchKernelGGL(enc_attn16_kernel<false>, dim3((n_sent + 3) / 4), dim3(256), 0, st, qkv, sent_off, n_sent, R, att);
+        hipLaunchKernelGGL(enc_attn16_kernel<false>, dim3((n_sent + 3) / 4), dim3(256), 0, st, src, sent_off, n_sent, R, att);
       if (max_sent_len > 16) {
         if (w->gemm_format == ST_GEMM_F16X3)
-          hipLaunchKernelGGL(enc_attn_kernel<true>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, R, att);
+          hipLaunchKernelGGL(enc_attn_kernel<true>, dim3(n_sent), dim3(256), 0, st, src, sent_off, R, att);
         else
-          hipLaunchKernelGGL(enc_attn_kernel<false>, dim3(n_sent), dim3(256), 0, st, qkv, sent_off, R, att);
+          hipLaunchKernelGGL(enc_attn_kernel<false>, dim3(n_sent), dim3(256), 0, st, src, sent_off, R, att);
       }
       ST_LAUNCH_CHECK();
     }

@@ -66,6 +66,7 @@ ST_RP_SWITCH(rp_enc_unfused, 0);      // ST_AB_ENC_UNFUSED: encoder QKV and atte
 ST_RP_SWITCH(rp_dec_fused, 0);        // ST_AB_DEC_FUSED: decode QKV + attention in one kernel (measured negative, st_decode.hip)
 ST_RP_SWITCH(rp_no_emb_in_tail, 0);   // ST_AB_EMBED_KERNEL: the decode step's embed kernel writes x for the first layer's half-layer kernel
 ST_RP_SWITCH(rp_kv_pos_major, 0);     // ST_AB_KV_POS_MAJOR: K / V cache as [layer][k|v][position][job] instead of [job][layer][k|v][position] (measured: no difference)
+ST_RP_SWITCH(rp_enc_tab_gather, 0);   // ST_AB_ENC_TAB_GATHER: unfused encoder, first layer: the table rows are gathered into the qkv buffer first
 #undef ST_RP_SWITCH
 static inline void rp_ab_env() {
   static const bool done = [] {
@@ -80,6 +81,7 @@ static inline void rp_ab_env() {
     if (getenv("ST_AB_TAIL_MIN_ROWS")) rp_tail_min_rows = atoi(getenv("ST_AB_TAIL_MIN_ROWS"));
     if (getenv("ST_AB_ENC_UNFUSED")) rp_enc_unfused = 1;
     if (getenv("ST_AB_KV_POS_MAJOR")) rp_kv_pos_major = 1;
+    if (getenv("ST_AB_ENC_TAB_GATHER")) rp_enc_tab_gather = 1;
     if (getenv("ST_AB_DEC_FUSED")) rp_dec_fused = 1;
     if (getenv("ST_AB_EMBED_KERNEL")) rp_no_emb_in_tail = 1;
     return true;

@@ -737,6 +737,20 @@ def test_mixed_length_chunks_encoded_apart_give_the_same_latents(dev, ae):
         lat[split] = r.encode_prepared(prep).cpu().numpy()
     a, b = lat[True], lat[False]
     assert a.shape == b.shape == (n, 256) and np.isfinite(a).all()
+    if ae.gemm_format == "f16x3":
+        # the unsplit chunks' first layer read the (token, position) table rows where they lie; gathered into the q / k / v
+        # buffer first (the form behind ST_AB_ENC_TAB_GATHER) the same values reach the same kernels
+        import ctypes as C
+        from style_transfer_amd import _lib
+        sw = C.c_int.in_dll(_lib.lib(), "rp_enc_tab_gather")
+        sw.value = 1
+        try:
+            r = AttackRunner(ae, None, AttackConfig(split_by_length=False), dev)
+            r.ENC_CHUNK = 4096
+            g = r.encode_prepared(r.prepare(data)).cpu().numpy()
+        finally:
+            sw.value = 0
+        assert np.array_equal(g, b)
     long_ = lens > 16
     assert np.array_equal(a[long_], b[long_])
     err = np.abs(a[~long_] - b[~long_]).max(1) / np.linalg.norm(b[~long_], axis=1)
