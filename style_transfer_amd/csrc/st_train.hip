@@ -224,21 +224,47 @@ __global__ __launch_bounds__(256, 2) void tg_gemm_pair_kernel(TgArgs a, TgArgs b
 // The same product on a 128 x 128 tile per workgroup (64 x 64 per wave, contraction steps of 32): 4x the MFMA work per
 // LDS byte and per barrier.  Used when it still fills the chip (large batches); the 64 x 64 form above keeps the small ones.
 #define TG_LDW 36
+// VEC: four elements a load along each operand's unit-stride axis, as in tg_gemm_kernel (round 3: the sixteen one-element
+// loads per operand and stage, each with its 64-bit address and range test, cost as much as the stage's MFMAs)
+template <bool VEC>
 __global__ __launch_bounds__(256) void tg_gemm128_kernel(TgArgs a) {
   __shared__ __align__(16) float As[128 * TG_LDW], Bs[128 * TG_LDW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
   const int r0 = blockIdx.z * a.rper, r1 = min(a.R, r0 + a.rper);
   const bool a_r_fast = a.sar == 1, b_r_fast = a.sbr == 1;
-  float ra[16], rb[16];
+  constexpr int W = VEC ? 4 : 1, NG = 16 / W;
+  typedef float vecw __attribute__((ext_vector_type(W)));
+  vecw ra[NG], rb[NG];
+  // load q covers W elements from (r, i): r-fast operands run along r, the others along the tile
+  auto r_of = [&](int q, bool fast) {
+    const int e = tid + 256 * q;
+    if (VEC) return fast ? 4 * (e & 7) : (e >> 5);
+    return fast ? (e & 31) : (e >> 7);
+  };
+  auto i_of = [&](int q, bool fast) {
+    const int e = tid + 256 * q;
+    if (VEC) return fast ? (e >> 3) : 4 * (e & 31);
+    return fast ? (e >> 5) : (e & 127);
+  };
   auto fetch = [&](int rc) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int e = tid + 256 * q;
-      const int ar = a_r_fast ? (e & 31) : (e >> 7), ai = a_r_fast ? (e >> 5) : (e & 127);
-      const int br = b_r_fast ? (e & 31) : (e >> 7), bj = b_r_fast ? (e >> 5) : (e & 127);
-      ra[q] = (i0 + ai < a.M && rc + ar < r1) ? a.A[(long)(i0 + ai) * a.sai + (long)(rc + ar) * a.sar] : 0.0f;
-      rb[q] = (j0 + bj < a.N && rc + br < r1) ? a.B[(long)(rc + br) * a.sbr + (long)(j0 + bj) * a.sbj] : 0.0f;
+    for (int q = 0; q < NG; ++q) {
+      const int ar = r_of(q, a_r_fast), ai = i_of(q, a_r_fast);
+      const int br = r_of(q, b_r_fast), bj = i_of(q, b_r_fast);
+      ra[q] = (i0 + ai < a.M && rc + ar < r1) ? *(const vecw*)(a.A + (long)(i0 + ai) * a.sai + (long)(rc + ar) * a.sar) : vecw(0.0f);
+      rb[q] = (j0 + bj < a.N && rc + br < r1) ? *(const vecw*)(a.B + (long)(rc + br) * a.sbr + (long)(j0 + bj) * a.sbj) : vecw(0.0f);
+    }
+  };
+  auto stage_store = [&](float* T, bool fast, int q, vecw v) {  // LDS rows: tile index, TG_LDW apart; r runs along a row
+    float* d = T + i_of(q, fast) * TG_LDW + r_of(q, fast);
+    if (!VEC) {
+      d[0] = v[0];
+    } else if (fast) {
+      *(vecw*)d = v;
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) d[k * TG_LDW] = v[k];
     }
   };
   f32x16 acc[2][2];
@@ -253,12 +279,9 @@ __global__ __launch_bounds__(256) void tg_gemm128_kernel(TgArgs a) {
   for (int rc = r0; rc < r1; rc += 32) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int e = tid + 256 * q;
-      const int ar = a_r_fast ? (e & 31) : (e >> 7), ai = a_r_fast ? (e >> 5) : (e & 127);
-      const int br = b_r_fast ? (e & 31) : (e >> 7), bj = b_r_fast ? (e >> 5) : (e & 127);
-      As[ai * TG_LDW + ar] = ra[q];
-      Bs[bj * TG_LDW + br] = rb[q];
+    for (int q = 0; q < NG; ++q) {
+      stage_store(As, a_r_fast, q, ra[q]);
+      stage_store(Bs, b_r_fast, q, rb[q]);
     }
     __syncthreads();
     if (rc + 32 < r1) fetch(rc + 32);
@@ -496,12 +519,16 @@ __device__ __forceinline__ float tr_dy(const BnActArgs& a, long e, int g, int b,
   if (a.drop_p > 0.0f) d = tr_keep(a.mask, a.seed, tr_mask_index(g, a.layer, b, c, a.B, a.N), a.drop_p) ? d * (1.0f / (1.0f - a.drop_p)) : 0.0f;
   return y > 0.0f ? d : a.slope * d;
 }
-__global__ __launch_bounds__(64 * TR_RG) void tr_bn_bwd_sums_kernel(BnActArgs a) {
+// gridDim.z > 1 (large batches with few calls carrying gradient: one call of 8192 rows was 8 workgroups walking 512 rows a
+// thread, 244 us): block z sums rows [z rper, (z + 1) rper) into part[z][g][2][N] and tr_bn_bwd_sums_finish_kernel adds
+// the parts in order.
+__global__ __launch_bounds__(64 * TR_RG) void tr_bn_bwd_sums_kernel(BnActArgs a, int rper, float* __restrict__ part) {
   __shared__ float red[2][TR_RG][64];
   const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rg = threadIdx.x >> 6, g = blockIdx.y;
+  const int b_lo = blockIdx.z * rper, b_hi = min(a.B, b_lo + rper);
   float s1 = 0.0f, s2 = 0.0f;
   if (c < a.N)
-    for (int b = rg; b < a.B; b += TR_RG) {
+    for (int b = b_lo + rg; b < b_hi; b += TR_RG) {
       float xh;
       const float dy = tr_dy(a, ((long)g * a.B + b) * a.N + c, g, b, c, xh);
       s1 += dy;
@@ -511,14 +538,31 @@ __global__ __launch_bounds__(64 * TR_RG) void tr_bn_bwd_sums_kernel(BnActArgs a)
   red[1][rg][cl] = s2;
   __syncthreads();
   if (rg == 0 && c < a.N) {
-    float* o = (float*)a.sums + (long)g * 2 * a.N;
     const float sb = tr_rg_sum(red[0], cl), sg = tr_rg_sum(red[1], cl);
+    if (gridDim.z > 1) {
+      float* o = part + ((long)blockIdx.z * gridDim.y + g) * 2 * a.N;
+      o[c] = sb;
+      o[a.N + c] = sg;
+      return;
+    }
+    float* o = (float*)a.sums + (long)g * 2 * a.N;
     o[c] = sb;
     o[a.N + c] = sg;
     if (a.dbeta) {
       a.dbeta[c] = sb;
       a.dgamma[c] = sg;
     }
+  }
+}
+__global__ __launch_bounds__(256) void tr_bn_bwd_sums_finish_kernel(BnActArgs a, int G, int nz, const float* __restrict__ part) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // over [G][2][N]
+  if (e >= G * 2 * a.N) return;
+  float s = 0.0f;
+  for (int z = 0; z < nz; ++z) s += part[(long)z * G * 2 * a.N + e];
+  ((float*)a.sums)[e] = s;
+  if (a.dbeta) {  // (one call: e = k N + c)
+    if (e < a.N) a.dbeta[e] = s;
+    else a.dgamma[e - a.N] = s;
   }
 }
 // dH = gamma * inv / B * (B*dy - sum dy - xhat * sum dy*xhat)
@@ -735,7 +779,8 @@ int gemm(hipStream_t st, const float* A, long sai, long sar, const float* Bm, lo
   const TgArgs a = gemm_args(A, sai, sar, Bm, sbr, sbj, C, ldc, bias, M, N, R, nslab, slab, colsum);
   if (gemm_big(M, N, nslab)) {
     if (colsum) return ST_EINVAL;  // (the 128 x 128 form has no fused column sum: weight_grads checks)
-    hipLaunchKernelGGL(tg_gemm128_kernel, dim3((N + 127) / 128, (M + 127) / 128, nslab), dim3(256), 0, st, a);
+    if (gemm_vec(a)) hipLaunchKernelGGL(tg_gemm128_kernel<true>, dim3((N + 127) / 128, (M + 127) / 128, nslab), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(tg_gemm128_kernel<false>, dim3((N + 127) / 128, (M + 127) / 128, nslab), dim3(256), 0, st, a);
   } else {
     const bool vec = gemm_vec(a), wide = gemm_wide(M, N, nslab);
     const dim3 grid = wide ? dim3((N + 63) / 64, (M + 63) / 64, nslab) : dim3((N + 31) / 32, (M + 31) / 32, nslab);
@@ -825,6 +870,15 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
   // small; large batches keep the elementwise pass on the whole chip.  (The same fusion of the backward's sums and its
   // elementwise pass measured SLOWER at batch 128, 10.7 against 5.4 + 3.0 us: one call = 8 workgroups walk both passes.)
   const bool fuse_bn = B <= 512;
+  // BatchNorm backward sums of `calls` calls: rows split over workgroups until the grid fills the chip
+  auto bn_bwd_sums = [&](const BnActArgs& b, int col_blocks, int calls) {
+    const int want = (256 + col_blocks * calls - 1) / (col_blocks * calls), most = B / 256 > 1 ? B / 256 : 1;
+    const int nz = want < most ? want : most;
+    const int rper = ((B + nz - 1) / nz + TR_RG - 1) / TR_RG * TR_RG;
+    hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(col_blocks, calls, nz), dim3(64 * TR_RG), 0, st, b, rper, w.slabs);
+    if (nz > 1)
+      hipLaunchKernelGGL(tr_bn_bwd_sums_finish_kernel, dim3((calls * 2 * b.N + 255) / 256), dim3(256), 0, st, b, calls, nz, (const float*)w.slabs);
+  };
   auto bnargs = [&](const float* H, const float* mean, const float* var, int gofs, int bofs, float* A, int layer, int N, int rows, float slope, float dp) {
     BnActArgs a{};
     a.H = H; a.mean = mean; a.var = var; a.gamma = pr + gofs; a.beta = pr + bofs; a.A = A; a.mask = keep_masks; a.seed = seed;
@@ -886,7 +940,7 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
     TR_RUN(layer_grads(st, w, w.dP, w.Q, pr + ST_TP_P_FC2_W, B, 256, 100, gr + ST_TP_P_FC2_W, gr + ST_TP_P_FC2_B, w.dQ));
     BnActArgs bp = fp;
     bp.dA = w.dQ; bp.sums = w.sums; bp.dH = w.dQ; bp.dbeta = gr + ST_TP_P_BN_B; bp.dgamma = gr + ST_TP_P_BN_G;
-    hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(2, 1), dim3(64 * TR_RG), 0, st, bp);
+    bn_bwd_sums(bp, 2, 1);
     hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)B * 100), dim3(256), 0, st, bp);
     TR_RUN(layer_grads(st, w, w.dQ, w.Z, pr + ST_TP_P_FC1_W, B, 100, 256, gr + ST_TP_P_FC1_W, gr + ST_TP_P_FC1_B, w.dZ));
   }
@@ -898,7 +952,7 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
     b2.dbeta = gr + ST_TP_S_BN2_B;
     b2.dgamma = gr + ST_TP_S_BN2_G;
   }
-  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(64 * TR_RG), 0, st, b2);
+  bn_bwd_sums(b2, 8, Gb);
   hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)GbB * 512), dim3(256), 0, st, b2);
   if (Gb > 1) {  // d beta / d gamma: sum over the calls of sums[g][0] / sums[g][1]
     hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums, Gb, 1024L, 512L, gr + ST_TP_S_BN2_B);
@@ -912,7 +966,7 @@ extern "C" int st_scorer_train_step(const float* params, float* bn, const float*
     b1.dbeta = gr + ST_TP_S_BN1_B;
     b1.dgamma = gr + ST_TP_S_BN1_G;
   }
-  hipLaunchKernelGGL(tr_bn_bwd_sums_kernel, dim3(8, Gb), dim3(64 * TR_RG), 0, st, b1);
+  bn_bwd_sums(b1, 8, Gb);
   hipLaunchKernelGGL(tr_bn_bwd_apply_kernel, blocks((long)GbB * 512), dim3(256), 0, st, b1);
   if (Gb > 1) {  // d beta / d gamma: sum over the calls of sums[g][0] / sums[g][1]
     hipLaunchKernelGGL(tr_slab_sum_kernel, dim3(2), dim3(256), 0, st, w.sums, Gb, 1024L, 512L, gr + ST_TP_S_BN1_B);
