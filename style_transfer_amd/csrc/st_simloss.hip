@@ -201,7 +201,12 @@ int g_sl_small = 1;  // 0: small blocks through the GEMM path as well (tests fli
 // (the AE constraint, st_aetrain.hip): one forward and one backward launch for all of them instead of one pair per view
 // (at B = 128 a view's launches are 32 + 64 workgroups of 49 + 38 us: eleven views in a row were 18 % of the step).
 // loss_rows, lse: [n_views][B]; d_ori_parts: [n_views][B][256] (the caller adds them up in view order); d_like0 += per view.
-bool sl_small_views_ok(int B) { return g_sl_small && B <= SL_SMALL && B % 32 == 0; }
+// blocks up to this size go through sl_small_views (all views in one launch pair).  Beyond SL_SMALL a single view is faster
+// on the GEMM path, but eleven of them in one launch fill the chip: AE step at B = 256 6.92 -> 6.65 ms, B = 384 10.97 -> 9.37
+// (384 is no multiple of 256, its GEMM path is the chunked one); at B = 512 the wave-per-row loops lose, 11.05 -> 11.91
+// (tools/ae_views_limit_probe.py)
+int g_sl_small_views_max = 384;
+bool sl_small_views_ok(int B) { return g_sl_small && B <= g_sl_small_views_max && B % 32 == 0; }
 int sl_small_views(const float* ori, const float* like0, int n_views, int B, float tau, float* loss_rows, float* lse, const float* g,
                    float* d_ori_parts, float* d_like0, hipStream_t st) {
   ST_CHECK_ARG(sl_small_views_ok(B) && n_views >= 1 && n_views <= 65535 && tau > 0.0f, "sl_small_views: B=%d n_views=%d", B, n_views);
